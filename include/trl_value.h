@@ -1,0 +1,151 @@
+/*
+ * trl_value.h -- C ABI of the MI355X (gfx950) value-estimation library.
+ *
+ * This is the drop-in boundary for TorchRL's value-estimation hot path.  The reference
+ * (AsbjornLorenzen/torchrl v0.7.2) has no native code on this path: the functions below
+ * replace everything *below* the Python signatures of
+ *   torchrl/objectives/value/functional.py   (the ATen op soup of the loop / vec variants)
+ * and are loaded the way the reference loads its only native module
+ *   torchrl/_extension.py:17-31, setup.py:121-169  (`torchrl._torchrl` discovery convention).
+ * INTEGRATION.md shows the reference-side ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no torch types.  PyTorch (or any caller) owns every
+ *    buffer: inputs are read, caller-allocated outputs are written, nothing is retained.
+ *  - All pointers are DEVICE pointers (HIP).  Every tensor is the canonical contiguous
+ *    (O, T, I) view of a `[*B, T, *F]` tensor with time at `time_dim`:
+ *    O = prod(B), I = prod(F), element (o,t,i) at o*T*I + t*I + i.
+ *  - Masks (`done`, `terminated`) are one byte per element, 0 or 1 (torch.bool storage).
+ *  - `stream` is a hipStream_t (NULL = default stream).  Calls are asynchronous on that
+ *    stream; the library never synchronises the host and never allocates device memory.
+ *  - `val_dtype` is the dtype of reward/value tensors, `coef_dtype` the dtype the
+ *    reference's coefficient tensors (`gamma * int_mask`) would have: python-float gammas
+ *    are rounded to the torch default dtype even for float64 values (functional.py:172-174).
+ *    Scalar coefficients are passed as doubles that already hold the rounded value.
+ *    Arithmetic runs in promote(val_dtype, coef_dtype), op for op in the reference's order
+ *    (no FMA contraction).
+ *  - Return value: TRL_OK or an error code; `trl_last_error()` gives the message of the
+ *    last failure on the calling thread.  The host wrapper maps them to the reference's
+ *    Python exceptions.
+ */
+#ifndef TRL_VALUE_H
+#define TRL_VALUE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRL_ABI_VERSION 1
+
+enum { TRL_F32 = 0, TRL_F64 = 1 };
+
+enum {
+    TRL_OK = 0,
+    TRL_ERR_INVALID_ARGUMENT = 1, /* null pointer, non-positive size, bad dtype/algo */
+    TRL_ERR_UNSUPPORTED = 2,      /* combination not implemented by the chosen algorithm */
+    TRL_ERR_WORKSPACE = 3,        /* workspace missing or too small */
+    TRL_ERR_LAUNCH = 4            /* HIP reported a launch error */
+};
+
+/* Kernel family.  AUTO picks by shape. */
+enum {
+    TRL_ALGO_AUTO = 0,
+    TRL_ALGO_SEQ = 1, /* one lane per (o,i) row, sequential over t: bit-identical to the reference loop */
+    TRL_ALGO_SCAN = 2 /* wavefront scan of affine maps over time (I == 1): tolerance-level parity,
+                         bit-exact at done boundaries */
+};
+
+int trl_abi_version(void);
+const char *trl_last_error(void);
+/* Name of the kernel family the last successful call on this thread dispatched to. */
+const char *trl_last_kernel(void);
+
+/* Bytes of device workspace the calls below need for a problem of this size (per call). */
+size_t trl_workspace_bytes(int64_t O, int64_t T, int64_t I);
+
+/*
+ * Generalized advantage estimate.
+ * Replaces: generalized_advantage_estimate / vec_generalized_advantage_estimate
+ *           (torchrl/objectives/value/functional.py:121-182, 272-370).
+ *   delta_t = r_t + (gamma_t * (1-terminated_t)) * v'_t - v_t
+ *   A_t     = delta_t + A_{t+1} * (lg_t * (1-done_t)),  A_T = 0
+ *   value_target = A + v
+ * gamma_t / lg_t: optional per-element tensors (coef_dtype) of gamma and lmbda*gamma;
+ *   when gamma_t != NULL and lg_t == NULL, lg_t is formed as (coef)lmbda * gamma_t in-kernel
+ *   (what `lmbda * gamma` gives for a python-float lmbda).  When both are NULL the scalars
+ *   `gamma` and `lg` apply.
+ * stats (optional, device double[3]): receives {N, sum(A), sum(A^2)} accumulated in fp64 in a
+ *   fixed order (deterministic); needs `workspace` of trl_workspace_bytes().  It feeds
+ *   trl_normalize() (after an all-reduce when the batch is sharded over GPUs).
+ */
+int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype,
+                const void *reward, const void *state_value, const void *next_state_value,
+                const uint8_t *done, const uint8_t *terminated,
+                const void *gamma_t, const void *lg_t,
+                double gamma, double lmbda, double lg,
+                int64_t O, int64_t T, int64_t I,
+                void *advantage, void *value_target,
+                double *stats, void *workspace, size_t workspace_bytes, int algo);
+
+/*
+ * TD(lambda) return.
+ * Replaces: td_lambda_return_estimate / vec_td_lambda_return_estimate
+ *           (functional.py:783-889, 1030-1183).
+ *   v'_t <- v'_t * (1-terminated_t);  g = v'_{T-1}
+ *   for t = T-1..0:  g <- g*(1-done_t) + v'_t*done_t;  g = R_t = r_t + gamma_t*((1-lmbda_t)*v'_t + lmbda_t*g)
+ * gamma_t / lmbda_t: optional per-element tensors (coef_dtype), else scalars.
+ * rolling_gamma == 0: the O(T^2) variant (functional.py:877-887): R_k is the tail run with
+ *   gamma_k, lmbda_k held fixed; requires gamma_t or lmbda_t.
+ */
+int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype,
+                      const void *reward, const void *next_state_value,
+                      const uint8_t *done, const uint8_t *terminated,
+                      const void *gamma_t, const void *lmbda_t,
+                      double gamma, double lmbda, int rolling_gamma,
+                      int64_t O, int64_t T, int64_t I,
+                      void *returns, int algo);
+
+/*
+ * V-trace advantage and targets.
+ * Replaces: vtrace_advantage_estimate (functional.py:1270-1350).
+ *   rho = exp(log_pi - log_mu); rb = min(rho, rho_thresh); cb = min(rho, c_thresh)
+ *   x_t = rb_t*(r_t + gamma_t*(1-term_t)*v'_t - v_t) + (gamma_t*(1-done_t)*cb_t)*x_{t+1},  x_T = 0
+ *   vs = x + v;  vs+_t = vs_{t+1} (t < T-1), v'_{T-1} (t = T-1; the shift ignores done)
+ *   advantage = rb*(r + gamma*(1-term)*vs+ - v)
+ * Outputs have dtype promote(val_dtype, coef_dtype) (the reference allocates nothing in val_dtype).
+ */
+int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype,
+                   const void *log_pi, const void *log_mu,
+                   const void *state_value, const void *next_state_value, const void *reward,
+                   const uint8_t *done, const uint8_t *terminated,
+                   const void *gamma_t, double gamma, double rho_thresh, double c_thresh,
+                   int64_t O, int64_t T, int64_t I,
+                   void *advantage, void *vs, int algo);
+
+/*
+ * Advantage normalisation from precomputed statistics.
+ * Replaces: `(adv - adv.mean()) / adv.std().clamp_min(eps)`
+ *           (torchrl/objectives/value/advantages.py:1459-1463 GAE average_gae, eps 1e-4;
+ *            :1828-1832 VTrace average_adv, eps 1e-5; torchrl/_utils.py:901-912 _standardize, eps 1e-6).
+ * stats: device double[3] = {N, sum, sum of squares} over ALL elements (all ranks).
+ * mean = sum/N; std = sqrt((sumsq - N*mean^2)/(N-1)) (unbiased); both rounded to `dtype`,
+ * std clamped from below by eps, then out = (x - mean) / std in `dtype`.  out may alias x.
+ */
+int trl_normalize(void *stream, int dtype, const void *x, int64_t n,
+                  const double *stats, double eps, void *out);
+
+/*
+ * {N, sum, sumsq} of an arbitrary tensor (fp64 accumulation, fixed order) into stats[3];
+ * used for normalising V-trace advantages / TD(lambda) rewards and by tests.
+ * Needs `workspace` of trl_workspace_bytes(n, 1, 1).
+ */
+int trl_moments(void *stream, int dtype, const void *x, int64_t n,
+                double *stats, void *workspace, size_t workspace_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRL_VALUE_H */

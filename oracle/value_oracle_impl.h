@@ -1,0 +1,175 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU oracle for the value-estimation hot path.
+ *
+ * This file is a plain-C restatement of the reference's *sequential loops*
+ * (reference: torchrl/objectives/value/functional.py); it is included several
+ * times by value_oracle.c with different (TS, TG) type pairs.  It is never
+ * linked into, imported by or called from the product library (torchrl_amd/);
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * Type parameters (defined by the including file):
+ *   TS      storage dtype of reward / state_value / next_state_value / outputs
+ *   TG      dtype the reference's coefficient tensors have (gamma * int_mask);
+ *           float when gamma is a python float under default dtype float32,
+ *           whatever dtype a full gamma tensor has otherwise
+ *   TC      compute dtype = promote(TS, TG)
+ *   SFX     symbol suffix
+ *
+ * Layout: every tensor is the canonical contiguous (O, T, I) view, element
+ * (o,t,i) at o*T*I + t*I + i; masks are one byte per element (0/1).
+ * Build: gcc -O2 -ffp-contract=off (no FMA contraction: the reference rounds
+ * every product and sum separately).
+ */
+
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+#define FN(name) CAT(name, SFX)
+
+/* ---------------------------------------------------------------------------
+ * GAE -- functional.py:153-182 (generalized_advantage_estimate)
+ *   g_not_terminated = gamma * not_terminated                  (:172, dtype TG)
+ *   delta = reward + (g_not_terminated * nsv) - state_value    (:173, dtype TC)
+ *   discount = lmbda * gamma * not_done                        (:174, dtype TG)
+ *   for t reversed: prev = adv[t] = delta[t] + prev*discount[t] (:175-178)
+ *   value_target = advantage + state_value                     (:180, dtype TS)
+ * gamma_t / lg_t (optional) are full (O,T,I) tensors of gamma and lmbda*gamma;
+ * when NULL the scalars gamma / lg (already rounded to TG by the caller) apply.
+ * `prev` keeps the promoted dtype TC across iterations because of the chained
+ * assignment at :176 (only the stored advantage is rounded to TS).
+ * ------------------------------------------------------------------------- */
+void FN(oracle_gae_)(const TS *reward, const TS *value, const TS *next_value,
+                     const unsigned char *done, const unsigned char *terminated,
+                     const TG *gamma_t, const TG *lg_t, double gamma, double lg,
+                     long O, long T, long I, TS *advantage, TS *value_target)
+{
+    for (long o = 0; o < O; ++o) {
+        for (long i = 0; i < I; ++i) {
+            TC prev = (TC)0;
+            int first = 1;
+            for (long t = T - 1; t >= 0; --t) {
+                long j = (o * T + t) * I + i;
+                TG g = gamma_t ? gamma_t[j] : (TG)gamma;
+                TG c = lg_t ? lg_t[j] : (TG)lg;
+                TG g_nt = g * (TG)(terminated[j] ? 0 : 1);
+                TG disc = c * (TG)(done[j] ? 0 : 1);
+                TC gv = (TC)g_nt * (TC)next_value[j];
+                TC delta = ((TC)reward[j] + gv) - (TC)value[j];
+                TC carry;
+                if (first) {
+                    /* python int 0 * discount -> dtype TG, value 0*disc */
+                    carry = (TC)((TG)0 * disc);
+                    first = 0;
+                } else {
+                    carry = prev * (TC)disc;
+                }
+                prev = delta + carry;
+                advantage[j] = (TS)prev;
+                value_target[j] = (TS)(advantage[j] + value[j]);
+            }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * TD(lambda) return -- functional.py:836-889 (td_lambda_return_estimate)
+ *   nsv = next_state_value * not_terminated                     (:844)
+ *   gamma, lmbda -> full tensors (:850-857); TG is their dtype (== TS when the
+ *   caller passed python floats: torch.full_like(nsv, gamma))
+ *   rolling (:865-876):
+ *     g = nsv[T-1]
+ *     for i reversed: g = g*(1-dn) + nv*dn
+ *                     g = ret[i] = r[i] + gamma[i]*((1-lmd)*nv + lmd*g)
+ *   not rolling (:877-887): for every start k rerun the tail with gamma[k],
+ *   lmbda[k] held fixed (O(T^2)).
+ * ------------------------------------------------------------------------- */
+void FN(oracle_td_lambda_)(const TS *reward, const TS *next_value,
+                           const unsigned char *done, const unsigned char *terminated,
+                           const TG *gamma_t, const TG *lmbda_t, double gamma, double lmbda,
+                           int rolling, long O, long T, long I, TS *returns)
+{
+    for (long o = 0; o < O; ++o) {
+        for (long i = 0; i < I; ++i) {
+            long jl = (o * T + (T - 1)) * I + i;
+            TS nv_last = next_value[jl] * (TS)(terminated[jl] ? 0 : 1);
+            if (rolling) {
+                TC g = (TC)nv_last;
+                for (long t = T - 1; t >= 0; --t) {
+                    long j = (o * T + t) * I + i;
+                    TS dn = (TS)(done[j] ? 1 : 0);
+                    TS omd = (TS)(done[j] ? 0 : 1);
+                    TS nv = next_value[j] * (TS)(terminated[j] ? 0 : 1);
+                    TG gm = gamma_t ? gamma_t[j] : (TG)gamma;
+                    TG lm = lmbda_t ? lmbda_t[j] : (TG)lmbda;
+                    TG oml = (TG)1 - lm;
+                    g = g * (TC)omd + (TC)(nv * dn);
+                    g = (TC)reward[j] + (TC)gm * ((TC)oml * (TC)nv + (TC)lm * g);
+                    returns[j] = (TS)g;
+                }
+            } else {
+                for (long k = 0; k < T; ++k) {
+                    long jk = (o * T + k) * I + i;
+                    TG gm = gamma_t ? gamma_t[jk] : (TG)gamma;
+                    TG lm = lmbda_t ? lmbda_t[jk] : (TG)lmbda;
+                    TG oml = (TG)1 - lm;
+                    TC g = (TC)nv_last;
+                    for (long t = T - 1; t >= k; --t) {
+                        long j = (o * T + t) * I + i;
+                        TS dn = (TS)(done[j] ? 1 : 0);
+                        TS omd = (TS)(done[j] ? 0 : 1);
+                        TS nv = next_value[j] * (TS)(terminated[j] ? 0 : 1);
+                        g = g * (TC)omd + (TC)(nv * dn);
+                        g = (TC)reward[j] + (TC)gm * ((TC)oml * (TC)nv + (TC)lm * g);
+                    }
+                    returns[jk] = (TS)g;
+                }
+            }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * V-trace -- functional.py:1306-1350 (vtrace_advantage_estimate)
+ *   done_discounts = gamma*not_done, terminated_discounts = gamma*not_term (:1322-1323, TG)
+ *   rho = exp(log_pi - log_mu); clipped_rho = min(rho, rho_thresh)         (:1325-1326)
+ *   deltas = clipped_rho * (r + td*nsv - v); clipped_c = min(rho, c_thresh) (:1327-1330)
+ *   x = delta_t + (dd_t*c_t)*x  reversed in time, x_T = 0                   (:1332-1339)
+ *   vs = x + v; vs_next = [vs[1:], nsv[T-1]]  (shift ignores done)          (:1342-1345)
+ *   adv = clipped_rho * (r + td*vs_next - v)                                (:1346-1348)
+ * Outputs have dtype TC (the reference allocates nothing in TS here).
+ * clamp_max propagates NaN (torch.clamp semantics).
+ * ------------------------------------------------------------------------- */
+static inline TC FN(clamp_max_)(TC x, TC hi) { return (x != x) ? x : (x > hi ? hi : x); }
+
+void FN(oracle_vtrace_)(const TS *log_pi, const TS *log_mu, const TS *value, const TS *next_value,
+                        const TS *reward, const unsigned char *done, const unsigned char *terminated,
+                        const TG *gamma_t, double gamma, double rho_thresh, double c_thresh,
+                        long O, long T, long I, TC *advantage, TC *vs_out)
+{
+    for (long o = 0; o < O; ++o) {
+        for (long i = 0; i < I; ++i) {
+            TC x = (TC)0;
+            TC vs_next = (TC)next_value[(o * T + (T - 1)) * I + i];
+            for (long t = T - 1; t >= 0; --t) {
+                long j = (o * T + t) * I + i;
+                TG g = gamma_t ? gamma_t[j] : (TG)gamma;
+                TG dd = g * (TG)(done[j] ? 0 : 1);
+                TG td = g * (TG)(terminated[j] ? 0 : 1);
+                TS lr = log_pi[j] - log_mu[j];
+                TS rho = (sizeof(TS) == 4) ? (TS)expf((float)lr) : (TS)exp((double)lr);
+                /* thresholds are 0-dim tensors in the reference: they do not promote rho */
+                TS crho = (TS)FN(clamp_max_)((TC)rho, (TC)(TS)rho_thresh);
+                TS cc = (TS)FN(clamp_max_)((TC)rho, (TC)(TS)c_thresh);
+                TC delta = (TC)crho * (((TC)reward[j] + (TC)td * (TC)next_value[j]) - (TC)value[j]);
+                x = delta + ((TC)dd * (TC)cc) * x;
+                TC vs = x + (TC)value[j];
+                advantage[j] = (TC)crho * (((TC)reward[j] + (TC)td * vs_next) - (TC)value[j]);
+                vs_out[j] = vs;
+                vs_next = vs;
+            }
+        }
+    }
+}
+
+#undef FN
+#undef CAT
+#undef CAT_

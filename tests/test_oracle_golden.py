@@ -1,0 +1,82 @@
+"""CPU: pin the oracle (oracle/value_oracle.c) against the golden fixtures generated from the
+reference, and -- when /root/reference is present (build container only) -- against the
+reference itself on fresh random inputs.  GAE and TD(lambda) are elementwise mul/add/sub only,
+so the oracle must be BIT-IDENTICAL; V-trace goes through exp(), pinned to a few ulp."""
+import pytest
+import torch
+
+import golden_util as G
+from oracle import value_oracle as O
+
+
+@pytest.mark.parametrize("meta", G.cases("gae"), ids=G.ids("gae"))
+def test_gae_bit_exact(meta):
+    torch.set_default_dtype(G.DT[meta["default_dtype"]])
+    a = G.arrays("gae", meta)
+    done, term = G.expand_masks(meta, a)
+    adv, vt = O.gae(G.coef(meta, a, "gamma"), G.coef(meta, a, "lmbda"), a["state_value"], a["next_state_value"],
+                    a["reward"], done, term, **G.time_kw(meta))
+    assert adv.dtype == a["advantage"].dtype and adv.shape == a["advantage"].shape
+    assert torch.equal(adv, a["advantage"])
+    assert torch.equal(vt, a["value_target"])
+
+
+@pytest.mark.parametrize("meta", G.cases("td_lambda"), ids=G.ids("td_lambda"))
+def test_td_lambda_bit_exact(meta):
+    a = G.arrays("td_lambda", meta)
+    ret = O.td_lambda(G.coef(meta, a, "gamma"), G.coef(meta, a, "lmbda"), a["next_state_value"], a["reward"],
+                      a["done"], a["terminated"], meta["rolling_gamma"], **G.time_kw(meta))
+    assert ret.dtype == a["returns"].dtype
+    assert torch.equal(ret, a["returns"])
+
+
+@pytest.mark.parametrize("meta", G.cases("vtrace"), ids=G.ids("vtrace"))
+def test_vtrace(meta):
+    a = G.arrays("vtrace", meta)
+    rho = torch.tensor(meta["rho_thresh"]) if meta["thresh_as_tensor"] else meta["rho_thresh"]
+    c = torch.tensor(meta["c_thresh"]) if meta["thresh_as_tensor"] else meta["c_thresh"]
+    adv, vs = O.vtrace(G.coef(meta, a, "gamma"), a["log_pi"], a["log_mu"], a["state_value"], a["next_state_value"],
+                       a["reward"], a["done"], a.get("terminated"), rho, c, **G.time_kw(meta))
+    assert adv.dtype == a["advantage"].dtype
+    tol = dict(rtol=2e-6, atol=2e-6) if adv.dtype == torch.float32 else dict(rtol=1e-14, atol=1e-14)
+    torch.testing.assert_close(adv, a["advantage"], **tol)
+    torch.testing.assert_close(vs, a["vs"], **tol)
+
+
+@pytest.mark.parametrize("meta", G.cases("normalise"), ids=G.ids("normalise"))
+def test_normalise(meta):
+    a = G.arrays("normalise", meta)
+    out = O.normalize(a["x"], meta["eps"])
+    tol = dict(rtol=2e-6, atol=2e-6) if out.dtype == torch.float32 else dict(rtol=1e-13, atol=1e-13)
+    torch.testing.assert_close(out, a["out"], **tol)
+
+
+def _ref():
+    import ref_import
+
+    if not ref_import.available():
+        pytest.skip("reference tree not present (GPU box)")
+    return ref_import.load_functional()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("shape,time_dim", [((7, 50, 1), -2), ((4, 30, 3, 1), -3), ((3, 40, 2, 2), 1)])
+def test_oracle_vs_reference_live(dtype, shape, time_dim):
+    F = _ref()
+    g = torch.Generator().manual_seed(5)
+    r, v, nv = (torch.randn(shape, generator=g, dtype=dtype) for _ in range(3))
+    term = torch.rand(shape, generator=g) < 0.05
+    done = term | (torch.rand(shape, generator=g) < 0.05)
+    gam = (0.9 + 0.1 * torch.rand(shape, generator=g)).to(dtype)
+    for gamma in (0.99, gam):
+        adv, vt = F.generalized_advantage_estimate(gamma, 0.95, v, nv, r, done, term, time_dim=time_dim)
+        oadv, ovt = O.gae(gamma, 0.95, v, nv, r, done, term, time_dim=time_dim)
+        assert torch.equal(adv, oadv) and torch.equal(vt, ovt)
+        ret = F.td_lambda_return_estimate(gamma, 0.95, nv, r, done, term, time_dim=time_dim)
+        assert torch.equal(ret, O.td_lambda(gamma, 0.95, nv, r, done, term, time_dim=time_dim))
+    lp, lm = torch.rand(shape, generator=g, dtype=dtype).log(), torch.rand(shape, generator=g, dtype=dtype).log()
+    adv, vs = F.vtrace_advantage_estimate(0.99, lp, lm, v, nv, r, done, term, time_dim=time_dim)
+    oadv, ovs = O.vtrace(0.99, lp, lm, v, nv, r, done, term, time_dim=time_dim)
+    tol = dict(rtol=2e-6, atol=2e-6) if dtype == torch.float32 else dict(rtol=1e-14, atol=1e-14)
+    torch.testing.assert_close(adv, oadv, **tol)
+    torch.testing.assert_close(vs, ovs, **tol)
