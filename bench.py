@@ -1,0 +1,155 @@
+"""Benchmark of the north-star step: GAE + advantage normalisation at [65536 envs x 32 steps] fp32.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" is one pass of the hot path over one batch of synthetic rollouts already resident in
+HBM: trl_gae_fwd (fused delta + scan + value_target + fp64 moments) -> [N > 1: one RCCL
+all-reduce of the 3 fp64 moments] -> trl_normalize (in place).  Every rank owns a full
+[65536 x 32] batch (weak scaling: the env dimension is sharded, nothing else is exchanged).
+Rank 0 prints ONE JSON line (schema in the task contract) with `roofline` for the dominant
+kernel (the GAE scan) and `cpu_baseline` (the CPU oracle timed on this host, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from torchrl_amd.objectives.value import functional as F  # noqa: E402
+
+O_ENVS, T_STEPS = 65536, 32
+GAMMA, LMBDA, EPS = 0.99, 0.95, 1e-4
+BYTES_PER_TRANSITION = 22  # fp32 GAE: 3x4 B + 2x1 B read, 2x4 B written; normalise adds no compulsory traffic
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_inputs(dev, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    shape = (O_ENVS, T_STEPS, 1)
+    r, v, nv = (torch.randn(shape, generator=g) for _ in range(3))
+    term = torch.rand(shape, generator=g) < 0.01
+    done = term | (torch.rand(shape, generator=g) < 0.01)
+    return tuple(t.to(dev) for t in (r, v, nv, done, term))
+
+
+def cpu_baseline(r, v, nv, done, term):
+    """CPU oracle (scalar C restatement of the reference loop + normalise), 1 thread."""
+    from oracle import value_oracle as O
+
+    O.build()
+    best = float("inf")
+    reps = 0
+    t_end = time.perf_counter() + 12.0
+    while reps < 5 or (time.perf_counter() < t_end and reps < 200):
+        t0 = time.perf_counter()
+        adv, _ = O.gae(GAMMA, LMBDA, v, nv, r, done, term)
+        O.normalize(adv, EPS)
+        best = min(best, time.perf_counter() - t0)
+        reps += 1
+    return {
+        "value": O_ENVS * T_STEPS / best,
+        "unit": "transitions/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"full [{O_ENVS}x{T_STEPS}] fp32 GAE+normalise workload, min of {reps} runs of oracle/value_oracle.c "
+                  f"(bit-identical restatement of the reference loop), host has {os.cpu_count()} cpus",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    if dist:
+        import torch.distributed as td
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    r, v, nv, done, term = make_inputs(dev, seed=rank)
+    call = F._prepare_gae(GAMMA, LMBDA, v, nv, r, done, term, -2)  # host canonicalisation: views only, no copies
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(k=None):
+        if k is not None:
+            ev[k][0].record()
+        adv, vt, stats = F._launch_gae(call, want_stats=True)
+        if k is not None:
+            ev[k][1].record()
+        if dist:
+            td.all_reduce(stats)
+        F.normalize_(adv, stats, EPS)
+        return adv, vt
+
+    for _ in range(args.warmup):
+        step()
+    kernel_name = F.last_kernel()
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        n_trans = O_ENVS * T_STEPS
+        gae_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps  # GAE entry point (scan + moments reduce)
+        achieved = n_trans * BYTES_PER_TRANSITION / (gae_ms * 1e-3) / 1e9
+        out = {
+            "metric": "GAE transitions/sec + % HBM roofline at 65536x32",
+            "value": world * n_trans * args.steps / dt,
+            "unit": "transitions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"GAE(gamma={GAMMA},lmbda={LMBDA})+normalise(eps={EPS}) [{O_ENVS} envs x {T_STEPS} steps] fp32 per GPU",
+                       "per_gpu_transitions": n_trans, "parallelism": f"env-sharded x{world}",
+                       "collective": "all_reduce(3 x f64)" if dist else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel_name,
+                         "kernel_ms": gae_ms, "bytes_per_launch": n_trans * BYTES_PER_TRANSITION},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(*(t.cpu() for t in (r, v, nv, done, term)))
+        print(json.dumps(out))
+    if dist:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

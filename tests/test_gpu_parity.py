@@ -1,0 +1,235 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (ctypes), against
+  (a) the golden fixtures generated from the reference (tests/golden), and
+  (b) the CPU oracle on seeded inputs.
+Bars: SEQ family bit-identical to the reference loop; SCAN family fp32 rtol=atol=1e-5, fp64
+rtol=atol=1e-12, and bit-exact wherever `done` is set (the carry is annihilated there)."""
+import pytest
+import torch
+
+import golden_util as G
+from oracle import value_oracle as O
+from torchrl_amd.objectives.value import functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SEQ, SCAN = F.ALGO_SEQ, F.ALGO_SCAN
+
+
+def tol(dtype):
+    return dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-12, atol=1e-12)
+
+
+def cu(x):
+    return x.to(DEV) if isinstance(x, torch.Tensor) else x
+
+
+def check(out, ref, exact, done=None):
+    out = out.cpu()
+    assert out.dtype == ref.dtype and out.shape == ref.shape
+    if exact:
+        assert torch.equal(out, ref), f"max abs diff {(out - ref).abs().max().item()}"
+    else:
+        torch.testing.assert_close(out, ref, **tol(ref.dtype))
+        if done is not None:
+            assert torch.equal(out[done], ref[done]), "done boundaries must be bit-exact"
+
+
+def algos(I):
+    return [SEQ, SCAN] if I == 1 else [SEQ]
+
+
+@pytest.mark.parametrize("meta", G.cases("gae"), ids=G.ids("gae"))
+def test_gae_golden(meta):
+    torch.set_default_dtype(G.DT[meta["default_dtype"]])
+    a = G.arrays("gae", meta)
+    done, term = G.expand_masks(meta, a)
+    call = F._prepare_gae(cu(G.coef(meta, a, "gamma")), cu(G.coef(meta, a, "lmbda")), cu(a["state_value"]),
+                          cu(a["next_state_value"]), cu(a["reward"]), cu(done), cu(term), meta["time_dim"])
+    for algo in algos(call.I):
+        adv, vt, _ = F._launch_gae(call, algo=algo)
+        check(adv, a["advantage"], algo == SEQ, a["done"])
+        check(vt, a["value_target"], algo == SEQ, a["done"])
+    # public entry points (AUTO dispatch), loop and vec names
+    for fn in (F.generalized_advantage_estimate, F.vec_generalized_advantage_estimate):
+        adv, vt = fn(cu(G.coef(meta, a, "gamma")), cu(G.coef(meta, a, "lmbda")), cu(a["state_value"]),
+                     cu(a["next_state_value"]), cu(a["reward"]), cu(done), cu(term), **G.time_kw(meta))
+        check(adv, a["advantage"], False, a["done"])
+        check(vt, a["value_target"], False, a["done"])
+
+
+@pytest.mark.parametrize("meta", G.cases("td_lambda"), ids=G.ids("td_lambda"))
+def test_td_lambda_golden(meta):
+    a = G.arrays("td_lambda", meta)
+    call = F._prepare_td_lambda(cu(G.coef(meta, a, "gamma")), cu(G.coef(meta, a, "lmbda")), cu(a["next_state_value"]),
+                                cu(a["reward"]), cu(a["done"]), cu(a["terminated"]), meta["rolling_gamma"], meta["time_dim"])
+    for algo in algos(call.I):
+        if algo == SCAN and not call.rolling:
+            continue
+        ret = F._launch_td_lambda(call, a["returns"].dtype, algo=algo)
+        check(ret, a["returns"], algo == SEQ)
+    ret = F.td_lambda_return_estimate(cu(G.coef(meta, a, "gamma")), cu(G.coef(meta, a, "lmbda")), cu(a["next_state_value"]),
+                                      cu(a["reward"]), cu(a["done"]), cu(a["terminated"]), meta["rolling_gamma"], **G.time_kw(meta))
+    check(ret, a["returns"], False)
+
+
+@pytest.mark.parametrize("meta", G.cases("vtrace"), ids=G.ids("vtrace"))
+def test_vtrace_golden(meta):
+    a = G.arrays("vtrace", meta)
+    rho = torch.tensor(meta["rho_thresh"]) if meta["thresh_as_tensor"] else meta["rho_thresh"]
+    c = torch.tensor(meta["c_thresh"]) if meta["thresh_as_tensor"] else meta["c_thresh"]
+    call = F._prepare_vtrace(cu(G.coef(meta, a, "gamma")), cu(a["log_pi"]), cu(a["log_mu"]), cu(a["state_value"]),
+                             cu(a["next_state_value"]), cu(a["reward"]), cu(a["done"]), cu(a.get("terminated")),
+                             rho, c, meta["time_dim"])
+    for algo in algos(call.I):
+        adv, vs = F._launch_vtrace(call, algo=algo)
+        check(adv, a["advantage"], False)
+        check(vs, a["vs"], False)
+    adv, vs = F.vtrace_advantage_estimate(cu(G.coef(meta, a, "gamma")), cu(a["log_pi"]), cu(a["log_mu"]),
+                                          cu(a["state_value"]), cu(a["next_state_value"]), cu(a["reward"]), cu(a["done"]),
+                                          cu(a.get("terminated")), rho, c, time_dim=meta["time_dim"])
+    check(adv, a["advantage"], False)
+    check(vs, a["vs"], False)
+
+
+@pytest.mark.parametrize("meta", G.cases("normalise"), ids=G.ids("normalise"))
+def test_normalise_golden(meta):
+    a = G.arrays("normalise", meta)
+    x = cu(a["x"])
+    st = F.moments(x)
+    ost = O.normalize(a["x"], meta["eps"], return_stats=True)[1]
+    torch.testing.assert_close(st.cpu(), ost, rtol=1e-13, atol=0)
+    out = F.normalize_(x.clone(), st, meta["eps"])
+    t = dict(rtol=1e-5, atol=1e-5) if a["out"].dtype == torch.float32 else dict(rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(out.cpu(), a["out"], **t)
+    torch.testing.assert_close(F.standardize(x, meta["eps"]).cpu(), a["out"], **t)
+
+
+def _rand_inputs(shape, dtype, seed, p_term=0.02, p_trunc=0.02):
+    g = torch.Generator().manual_seed(seed)
+    r, v, nv = (torch.randn(shape, generator=g, dtype=torch.float32).to(dtype) for _ in range(3))
+    term = torch.rand(shape, generator=g) < p_term
+    done = term | (torch.rand(shape, generator=g) < p_trunc)
+    gam = (0.9 + 0.1 * torch.rand(shape, generator=g)).to(dtype)
+    lp = torch.rand(shape, generator=g).clamp_min(1e-6).log().to(dtype)
+    lm = torch.rand(shape, generator=g).clamp_min(1e-6).log().to(dtype)
+    return r, v, nv, done, term, gam, lp, lm
+
+
+# shapes chosen to hit: SHORT wave-independent (T | 256), SHORT with cross-wave carry, ragged rows
+# (T % 4 != 0 -> unaligned path / row tails), single block, LONG rows (several chunks, partial chunk)
+SCAN_SHAPES = [(64, 32, 1), (300, 32, 1), (37, 100, 1), (5, 7, 1), (33, 3, 1), (9, 1, 1), (1, 2048, 1), (3, 2500, 1),
+               (2, 4099, 1), (130, 128, 1), (16, 1024, 1), (7, 1025, 1)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", SCAN_SHAPES, ids=[f"{s[0]}x{s[1]}" for s in SCAN_SHAPES])
+@pytest.mark.parametrize("tensor_gamma", [False, True], ids=["g_scalar", "g_tensor"])
+def test_all_estimators_vs_oracle(shape, dtype, tensor_gamma):
+    r, v, nv, done, term, gam, lp, lm = _rand_inputs(shape, dtype, seed=hash(shape) % 1000)
+    gamma = gam if tensor_gamma else 0.99
+    oadv, ovt = O.gae(gamma, 0.95, v, nv, r, done, term)
+    oret = O.td_lambda(gamma, 0.95, nv, r, done, term)
+    ova, ovs = O.vtrace(gamma, lp, lm, v, nv, r, done, term)
+    gcall = F._prepare_gae(cu(gamma), 0.95, cu(v), cu(nv), cu(r), cu(done), cu(term), -2)
+    tcall = F._prepare_td_lambda(cu(gamma), 0.95, cu(nv), cu(r), cu(done), cu(term), None, -2)
+    vcall = F._prepare_vtrace(cu(gamma), cu(lp), cu(lm), cu(v), cu(nv), cu(r), cu(done), cu(term), 1.0, 1.0, -2)
+    for algo in (SEQ, SCAN):
+        adv, vt, st = F._launch_gae(gcall, want_stats=True, algo=algo)
+        assert ("scan" in F.last_kernel()) == (algo == SCAN)
+        check(adv, oadv, algo == SEQ, done)
+        check(vt, ovt, algo == SEQ, done)
+        a64 = adv.double()
+        ref_st = torch.stack([torch.tensor(float(a64.numel()), device=DEV), a64.sum(), (a64 * a64).sum()])
+        torch.testing.assert_close(st, ref_st, rtol=1e-12, atol=1e-9)
+        check(F._launch_td_lambda(tcall, dtype, algo=algo), oret, algo == SEQ)
+        va, vs = F._launch_vtrace(vcall, algo=algo)
+        check(va, ova, False)
+        check(vs, ovs, False)
+
+
+@pytest.mark.parametrize("shape,time_dim", [((40, 50, 5, 1), -3), ((6, 9, 2, 5), 1), ((33, 17, 64), -2), ((4, 300, 130), -2)])
+def test_seq_multifeature_vs_oracle(shape, time_dim):
+    r, v, nv, done, term, gam, lp, lm = _rand_inputs(shape, torch.float32, seed=11)
+    adv, vt = F.generalized_advantage_estimate(0.9, 0.9, cu(v), cu(nv), cu(r), cu(done), cu(term), time_dim=time_dim)
+    oadv, ovt = O.gae(0.9, 0.9, v, nv, r, done, term, time_dim=time_dim)
+    check(adv, oadv, True)
+    check(vt, ovt, True)
+    ret = F.td_lambda_return_estimate(gam.to(DEV), 0.9, cu(nv), cu(r), cu(done), cu(term), time_dim=time_dim)
+    check(ret, O.td_lambda(gam, 0.9, nv, r, done, term, time_dim=time_dim), True)
+    va, vs = F.vtrace_advantage_estimate(0.9, cu(lp), cu(lm), cu(v), cu(nv), cu(r), cu(done), cu(term), time_dim=time_dim)
+    ova, ovs = O.vtrace(0.9, lp, lm, v, nv, r, done, term, time_dim=time_dim)
+    check(va, ova, False)
+    check(vs, ovs, False)
+
+
+def test_successive_trajectories_equal_concatenation():
+    """test_cost.py:14984-15135: a batch with a `terminated` at T//2-1 equals the two halves computed apart."""
+    T = 64
+    r, v, nv, done, term, gam, lp, lm = _rand_inputs((8, T, 1), torch.float32, seed=3, p_term=0.0, p_trunc=0.0)
+    term[:, T // 2 - 1] = True
+    done = term.clone()
+    h = T // 2
+    for algo in (SEQ, SCAN):
+        full = F._launch_gae(F._prepare_gae(0.99, 0.95, cu(v), cu(nv), cu(r), cu(done), cu(term), -2), algo=algo)[0]
+        a = F._launch_gae(F._prepare_gae(0.99, 0.95, cu(v[:, :h]), cu(nv[:, :h]), cu(r[:, :h]), cu(done[:, :h]), cu(term[:, :h]), -2), algo=algo)[0]
+        b = F._launch_gae(F._prepare_gae(0.99, 0.95, cu(v[:, h:]), cu(nv[:, h:]), cu(r[:, h:]), cu(done[:, h:]), cu(term[:, h:]), -2), algo=algo)[0]
+        torch.testing.assert_close(full, torch.cat([a, b], 1), rtol=1e-6, atol=1e-6)
+        fr = F._launch_td_lambda(F._prepare_td_lambda(0.99, 0.95, cu(nv), cu(r), cu(done), cu(term), None, -2), torch.float32, algo=algo)
+        ar = F._launch_td_lambda(F._prepare_td_lambda(0.99, 0.95, cu(nv[:, :h]), cu(r[:, :h]), cu(done[:, :h]), cu(term[:, :h]), None, -2), torch.float32, algo=algo)
+        br = F._launch_td_lambda(F._prepare_td_lambda(0.99, 0.95, cu(nv[:, h:]), cu(r[:, h:]), cu(done[:, h:]), cu(term[:, h:]), None, -2), torch.float32, algo=algo)
+        torch.testing.assert_close(fr, torch.cat([ar, br], 1), rtol=1e-6, atol=1e-6)
+
+
+def test_tdlambda_equals_gae_when_next_value_is_shifted_value():
+    """test_cost.py:13753-13822: TD(lambda) advantage == GAE advantage when next_value[t] = value[t+1]."""
+    g = torch.Generator().manual_seed(0)
+    v_all = torch.randn(6, 101, 1, generator=g)
+    v, nv = v_all[:, :-1].contiguous(), v_all[:, 1:].contiguous()
+    r = torch.randn(6, 100, 1, generator=g)
+    done = torch.zeros(6, 100, 1, dtype=torch.bool)
+    adv, _ = F.generalized_advantage_estimate(0.98, 0.94, cu(v), cu(nv), cu(r), cu(done))
+    tda = F.td_lambda_advantage_estimate(0.98, 0.94, cu(v), cu(nv), cu(r), cu(done))
+    vtda = F.vec_td_lambda_advantage_estimate(0.98, 0.94, cu(v), cu(nv), cu(r), cu(done))
+    torch.testing.assert_close(adv, tda, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(adv, vtda, rtol=1e-4, atol=1e-4)
+
+
+def test_reward2go_closed_form():
+    """functional.py:1381-1395 docstring known answer and test_cost.py:16287-16309 closed form."""
+    reward = torch.ones(1, 10, device=DEV)
+    done = torch.zeros(1, 10, dtype=torch.bool, device=DEV)
+    done[:, [3, 7]] = True
+    out = F.reward2go(reward, done, 0.99, time_dim=-1)
+    exp = torch.tensor([3.9404, 2.9701, 1.9900, 1.0, 3.9404, 2.9701, 1.9900, 1.0, 1.9900, 1.0], device=DEV).view(1, 10)
+    torch.testing.assert_close(out, exp, rtol=1e-4, atol=1e-4)
+
+
+def test_td1_matches_reference_semantics():
+    r, v, nv, done, term, gam, lp, lm = _rand_inputs((5, 40, 1), torch.float32, seed=21)
+    out = F.td1_return_estimate(0.97, cu(nv), cu(r), cu(done), cu(term)).cpu()
+    # reference loop, functional.py:538-549, restated inline for this small case
+    g = nv[:, -1].clone()
+    exp = torch.empty_like(r)
+    dnt = (done & ~term).float()
+    gnt = 0.97 * (~term).float()
+    for i in reversed(range(40)):
+        g = r[:, i] + gnt[:, i] * ((1 - dnt[:, i]) * g + dnt[:, i] * nv[:, i])
+        exp[:, i] = g
+    torch.testing.assert_close(out, exp, rtol=1e-5, atol=1e-5)
+
+
+def test_errors_on_device():
+    r = torch.randn(3, 8, 1, device=DEV)
+    d = torch.zeros(3, 8, 1, dtype=torch.bool, device=DEV)
+    with pytest.raises(RuntimeError, match="share a unique shape"):
+        F.generalized_advantage_estimate(0.9, 0.9, r, r, r[:, :4], d)
+    with pytest.raises(TypeError):
+        F.generalized_advantage_estimate(0.9, 0.9, r, r, r, d, d, -2)
+    with pytest.raises(RuntimeError, match="rolling_gamma=False is expected only"):
+        F.td_lambda_return_estimate(0.9, 0.9, r, r, d, rolling_gamma=False)
+    with pytest.raises(NotImplementedError, match="The vectorized version of TD"):
+        F.vec_td_lambda_return_estimate(torch.full_like(r, 0.9), 0.9, r, r, d, d, rolling_gamma=False)
+    tm = d.clone()
+    tm[:, 3] = True
+    with pytest.raises(NotImplementedError, match="When using rolling_gamma=False"):
+        F.vec_td_lambda_return_estimate(torch.full_like(r, 0.9), 0.9, r, r, tm, tm, rolling_gamma=False)

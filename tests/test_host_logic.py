@@ -1,0 +1,150 @@
+"""CPU: host-side logic of the drop-in (shape / time-dim errors, canonical (O,T,I) view,
+coefficient rounding) and the C-ABI library's exported symbols.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import golden_util as G
+from torchrl_amd import _extension
+from torchrl_amd.objectives.value import functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "trl_value.h")).read()
+    declared = set(re.findall(r"\b(trl_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_extension._PROTOTYPES), (declared ^ set(_extension._PROTOTYPES))
+    lib = ctypes.CDLL(_extension.lib_path())
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _extension.get_lib().trl_abi_version() == _extension.ABI_VERSION
+
+
+def test_cpu_tensors_fail_loudly():
+    r = torch.randn(3, 8, 1)
+    d = torch.zeros(3, 8, 1, dtype=torch.bool)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        F.generalized_advantage_estimate(0.9, 0.9, r, r, r, d)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        F.td_lambda_return_estimate(0.9, 0.9, r, r, d)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        F.vtrace_advantage_estimate(0.9, r, r, r, r, r, d)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_extension, "_lib", None)
+    monkeypatch.setattr(_extension, "_LIB_PATH", "/nonexistent/libtrl_value.so")
+    with pytest.raises(_extension.ExtensionMissingError):
+        _extension.get_lib()
+
+
+def test_error_table_matches_reference():
+    """Exception types / messages recorded from the reference (tests/golden/manifest.json: errors)."""
+    table = {e["name"]: e for e in G.MANIFEST["errors"]}
+    r = torch.randn(3, 8, 1)
+    d = torch.zeros(3, 8, 1, dtype=torch.bool)
+    g = torch.full_like(r, 0.9)
+    tm = d.clone()
+    tm[:, 3] = True
+    calls = {
+        "gae_shape_mismatch": lambda: F.generalized_advantage_estimate(0.9, 0.9, r, r, r[:, :4], d),
+        "gae_positional_time_dim": lambda: F.generalized_advantage_estimate(0.9, 0.9, r, r, r, d, d, -2),
+        "vec_gae_shape_mismatch": lambda: F.vec_generalized_advantage_estimate(0.9, 0.9, r, r, r[:, :4], d),
+        "gae_1d_time_dim_m3": lambda: F.generalized_advantage_estimate(0.9, 0.9, r[0, :, 0], r[0, :, 0], r[0, :, 0], d[0, :, 0], time_dim=-3),
+        "gae_bad_time_dim": lambda: F.generalized_advantage_estimate(0.9, 0.9, r, r, r, d, time_dim=-4),
+        "tdl_shape_mismatch": lambda: F.td_lambda_return_estimate(0.9, 0.9, r, r[:, :4], d),
+        "tdl_positional_time_dim": lambda: F.td_lambda_return_estimate(0.9, 0.9, r, r, d, d, None, -2),
+        "tdl_not_rolling_scalar": lambda: F.td_lambda_return_estimate(0.9, 0.9, r, r, d, rolling_gamma=False),
+        "vec_tdl_not_rolling_after_term": lambda: F.vec_td_lambda_return_estimate(g, 0.9, r, r, tm, tm, rolling_gamma=False),
+        "vec_tdl_not_rolling": lambda: F.vec_td_lambda_return_estimate(g, 0.9, r, r, d, d, rolling_gamma=False),
+        "vtrace_shape_mismatch": lambda: F.vtrace_advantage_estimate(0.9, r, r, r, r, r[:, :4], d),
+        "tdl_adv_shape_mismatch": lambda: F.td_lambda_advantage_estimate(0.9, 0.9, r[:, :4], r, r, d),
+    }
+    for name, fn in calls.items():
+        exp = table[name]
+        with pytest.raises(Exception) as ei:
+            fn()
+        assert type(ei.value).__name__ == exp["type"], (name, ei.value)
+        if exp["type"] != "TypeError":
+            assert str(ei.value) == exp["message"], name
+    # the reference fails on 1-D input with the default time_dim (ValueError from tuple unpacking); we raise too
+    with pytest.raises((RuntimeError, ValueError)):
+        F.generalized_advantage_estimate(0.9, 0.9, r[0, :, 0], r[0, :, 0], r[0, :, 0], d[0, :, 0])
+
+
+@pytest.mark.parametrize("shape,time_dim,exp", [((3, 8, 1), -2, (3, 8, 1)), ((4, 10, 5, 1), -3, (4, 10, 5)),
+                                                ((4, 10, 5, 1), 1, (4, 10, 5)), ((6, 9), -1, (6, 9, 1)),
+                                                ((17,), -1, (1, 17, 1)), ((2, 3, 4, 5), -2, (6, 4, 5)),
+                                                ((2, 3, 4, 5), 0, (1, 2, 60))])
+def test_canonical_view(shape, time_dim, exp):
+    assert F._canonical_dims(shape, time_dim)[:3] == exp
+
+
+def test_gae_coefficient_rounding_follows_reference():
+    """python-float gamma is rounded to the default dtype even for float64 values."""
+    r = torch.randn(3, 8, 1, dtype=torch.float64)
+    d = torch.zeros(3, 8, 1, dtype=torch.bool)
+    c = F._prepare_gae(0.99, 0.95, r, r, r, d, None, -2)
+    assert c.vdt == torch.float64 and c.cdt == torch.float32
+    assert c.gamma == float(torch.tensor(0.99, dtype=torch.float32)) and c.lg == float(torch.tensor(0.99 * 0.95, dtype=torch.float32))
+    c = F._prepare_gae(torch.tensor(0.99, dtype=torch.float64), 0.95, r, r, r, d, None, -2)
+    assert c.cdt == torch.float64 and c.gamma == 0.99 and c.lg == 0.99 * 0.95
+    torch.set_default_dtype(torch.float64)
+    c = F._prepare_gae(0.99, 0.95, r, r, r, d, None, -2)
+    assert c.cdt == torch.float64 and c.gamma == 0.99
+    torch.set_default_dtype(torch.float32)
+    # two 0-dim f32 buffers (the GAE module case) multiply in f32
+    g32, l32 = torch.tensor(0.97), torch.tensor(0.93)
+    c = F._prepare_gae(g32, l32, r, r, r, d, None, -2)
+    assert c.lg == float(g32 * l32)
+    # full tensor gamma, python lmbda: lmbda*gamma is formed in-kernel in gamma's dtype
+    gt = torch.rand(3, 8, 1)
+    c = F._prepare_gae(gt, 0.95, r, r, r, d, None, -2)
+    assert c.gamma_t is not None and c.lg_t is None and c.cdt == torch.float32 and c.lmbda == 0.95
+    # tensor lmbda: the product is materialised with torch's own rounding
+    c = F._prepare_gae(gt, torch.rand(3, 8, 1), r, r, r, d, None, -2)
+    assert c.lg_t is not None and c.gamma_t is not None
+
+
+def test_td_lambda_coefficients_keep_value_dtype():
+    """torch.full_like(next_state_value, gamma) keeps the value dtype."""
+    r = torch.randn(3, 8, 1, dtype=torch.float64)
+    d = torch.zeros(3, 8, 1, dtype=torch.bool)
+    c = F._prepare_td_lambda(0.99, 0.95, r, r, d, None, None, -2)
+    assert c.cdt == torch.float64 and c.gamma == 0.99 and c.lmbda == 0.95 and c.rolling
+    c = F._prepare_td_lambda(0.99, 0.95, r.float(), r.float(), d, None, None, -2)
+    assert c.gamma == float(torch.tensor(0.99, dtype=torch.float32))
+    c = F._prepare_td_lambda(torch.tensor(0.99), 0.95, r, r, d, None, None, -2)  # 0-dim f32 buffer: rounding comes from the buffer
+    assert c.gamma == float(torch.tensor(0.99, dtype=torch.float32))
+
+
+def test_expanded_masks_are_materialised():
+    r = torch.randn(4, 10, 5, 1)
+    d = (torch.rand(4, 10, 1, 1) < 0.2).expand(4, 10, 5, 1)
+    c = F._prepare_gae(0.9, 0.9, r, r, r, d, d, -3)
+    assert c.done.is_contiguous() and c.done.dtype == torch.uint8 and c.done.shape == r.shape
+    assert (c.O, c.T, c.I) == (4, 10, 5)
+
+
+def test_vtrace_thresholds_round_like_torch_tensor():
+    r = torch.randn(3, 8, 1, dtype=torch.float64)
+    d = torch.zeros(3, 8, 1, dtype=torch.bool)
+    c = F._prepare_vtrace(0.99, r, r, r, r, r, d, None, 0.7, 0.3, -2)
+    assert c.rho_thresh == float(torch.tensor(0.7)) and c.c_thresh == float(torch.tensor(0.3))
+    assert c.terminated.data_ptr() == c.done.data_ptr() or torch.equal(c.terminated, c.done)
+
+
+def test_transpose_time_decorator_contract():
+    @F._transpose_time
+    def f(x, *, time_dim=-2):
+        return x * 2
+
+    x = torch.randn(3, 4, 5)
+    assert f(x, time_dim=-3).shape == x.shape
+    assert f(torch.randn(7), time_dim=-1).shape == (7,)
+    with pytest.raises(RuntimeError, match="not compatible"):
+        f(torch.randn(7), time_dim=-3)

@@ -1,0 +1,107 @@
+"""Discovery and loading of the gfx950 value-estimation library.
+
+Mirrors the reference's extension convention (torchrl/_extension.py:17-31: probe for the
+native module at import time, warn -- never hard-fail -- if it is absent; consumers raise
+when they actually need it, torchrl/data/replay_buffers/samplers.py:23-37).  Here the native
+module is a plain C-ABI shared library (include/trl_value.h) loaded with ctypes: no torch
+headers, no pybind in the hot call.
+
+There is NO fallback implementation: every estimator in
+``torchrl_amd.objectives.value`` fails loudly (``ExtensionMissingError``) when the
+library cannot be loaded.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import warnings
+
+_LIB_NAME = "libtrl_value.so"
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
+ABI_VERSION = 1
+
+EXTENSION_WARNING = (
+    f"Failed to load the torchrl_amd HIP library ({_LIB_PATH}). The value estimators "
+    "(GAE / TD(lambda) / V-trace) will raise when called. Build it with "
+    "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C torchrl_amd/csrc` "
+    "(hipcc --offload-arch=gfx950)."
+)
+
+
+class ExtensionMissingError(RuntimeError):
+    pass
+
+
+_lib = None
+_load_error = None
+
+_vp, _i64, _dbl, _int, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int, ctypes.c_size_t
+
+# symbol -> (restype, argtypes); must list every entry point of include/trl_value.h
+_PROTOTYPES = {
+    "trl_abi_version": (_int, []),
+    "trl_last_error": (ctypes.c_char_p, []),
+    "trl_last_kernel": (ctypes.c_char_p, []),
+    "trl_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "trl_gae_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl,
+                           _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _int]),
+    "trl_td_lambda_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int,
+                                 _i64, _i64, _i64, _vp, _int]),
+    "trl_vtrace_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl,
+                              _i64, _i64, _i64, _vp, _vp, _int]),
+    "trl_normalize": (_int, [_vp, _int, _vp, _i64, _vp, _dbl, _vp]),
+    "trl_moments": (_int, [_vp, _int, _vp, _i64, _vp, _vp, _sz]),
+}
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def is_available() -> bool:
+    return os.path.exists(_LIB_PATH)
+
+
+def _load():
+    global _lib, _load_error
+    if _lib is not None:
+        return _lib
+    try:
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        got = lib.trl_abi_version()
+        if got != ABI_VERSION:
+            raise OSError(f"ABI version mismatch: library {got}, python {ABI_VERSION}")
+        _lib = lib
+    except (OSError, AttributeError) as e:  # missing file, missing symbol, missing HIP runtime
+        _load_error = e
+        _lib = None
+    return _lib
+
+
+def _init_extension():
+    """Called at package import (as torchrl/__init__.py:22,35 does): warn if the library is absent."""
+    if _load() is None:
+        warnings.warn(EXTENSION_WARNING + (f" [{_load_error}]" if _load_error else ""))
+
+
+def get_lib():
+    """Return the loaded library or raise loudly -- there is no fallback path."""
+    lib = _load()
+    if lib is None:
+        raise ExtensionMissingError(EXTENSION_WARNING + (f" [{_load_error}]" if _load_error else ""))
+    return lib
+
+
+class TrlError(RuntimeError):
+    """A C-ABI call returned a non-zero status."""
+
+
+def check(status: int, lib=None):
+    if status != 0:
+        lib = lib or get_lib()
+        msg = lib.trl_last_error().decode("utf-8", "replace")
+        raise TrlError(f"torchrl_amd native call failed (status {status}): {msg}")

@@ -1,0 +1,168 @@
+// extern "C" entry points declared in include/trl_value.h: argument validation, kernel-family
+// selection, error reporting.  No allocation, no host synchronisation, no torch types.
+#include "../../include/trl_value.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+thread_local const char *g_kernel = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(TRL_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return TRL_OK;
+}
+
+bool dtype_ok(int d) { return d == TRL_F32 || d == TRL_F64; }
+
+int check_dims(const char *fn, i64 O, i64 T, i64 I) {
+    if (O <= 0 || T <= 0 || I <= 0) return fail(TRL_ERR_INVALID_ARGUMENT, "%s: O, T, I must be positive (got %lld, %lld, %lld)", fn, O, T, I);
+    // element count must stay far from int64 overflow
+    const long double n = (long double)O * (long double)T * (long double)I;
+    if (n > 4.0e18L) return fail(TRL_ERR_INVALID_ARGUMENT, "%s: O*T*I too large", fn);
+    return TRL_OK;
+}
+
+i64 max_partials(i64 O, i64 T, i64 I) {
+    i64 a = seq_max_partials(O, T, I), b = scan_max_partials(O, T, I), c = moments_max_partials(O * T * I);
+    i64 m = a > b ? a : b;
+    return m > c ? m : c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int trl_abi_version(void) { return TRL_ABI_VERSION; }
+const char *trl_last_error(void) { return g_err; }
+const char *trl_last_kernel(void) { return g_kernel; }
+
+size_t trl_workspace_bytes(int64_t O, int64_t T, int64_t I) {
+    if (O <= 0 || T <= 0 || I <= 0) return 0;
+    return (size_t)max_partials(O, T, I) * 2 * sizeof(double) + 256;
+}
+
+int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
+                const void *next_state_value, const uint8_t *done, const uint8_t *terminated,
+                const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
+                int64_t O, int64_t T, int64_t I, void *advantage, void *value_target,
+                double *stats, void *workspace, size_t workspace_bytes, int algo) {
+    if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: bad dtype");
+    if (int rc = check_dims("trl_gae_fwd", O, T, I)) return rc;
+    if (!reward || !state_value || !next_state_value || !done || !terminated || !advantage || !value_target)
+        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: null tensor pointer");
+    if (lg_t && !gamma_t) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: lg_t given without gamma_t");
+    if (stats) {
+        if (!workspace || workspace_bytes < trl_workspace_bytes(O, T, I))
+            return fail(TRL_ERR_WORKSPACE, "trl_gae_fwd: stats requested but workspace is %zu bytes, need %zu",
+                        workspace_bytes, trl_workspace_bytes(O, T, I));
+        if (((uintptr_t)workspace & 7) != 0) return fail(TRL_ERR_WORKSPACE, "trl_gae_fwd: workspace must be 8-byte aligned");
+    }
+    GaeArgs a{reward, state_value, next_state_value, done, terminated, gamma_t, lg_t, gamma, lmbda, lg,
+              O, T, I, advantage, value_target, stats ? (double *)workspace : nullptr};
+    hipStream_t s = (hipStream_t)stream;
+    if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ)
+        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: unknown algo %d", algo);
+    LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
+    if (algo != TRL_ALGO_SEQ) res = launch_gae_scan(s, val_dtype, coef_dtype, a);
+    if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
+        return fail(TRL_ERR_UNSUPPORTED, "trl_gae_fwd: SCAN family does not support this shape (needs I == 1)");
+    if (res.status == TRL_ERR_UNSUPPORTED) res = launch_gae_seq(s, val_dtype, coef_dtype, a);
+    if (res.status != 0) return fail(res.status, "trl_gae_fwd: launch rejected (grid too large?)");
+    if (int rc = check_launch("trl_gae_fwd")) return rc;
+    if (stats) {
+        launch_reduce_partials(s, (const double *)workspace, res.npartials, (double)O * (double)T * (double)I, stats);
+        if (int rc = check_launch("trl_gae_fwd(stats)")) return rc;
+    }
+    g_kernel = res.kernel;
+    return TRL_OK;
+}
+
+int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *next_state_value,
+                      const uint8_t *done, const uint8_t *terminated, const void *gamma_t, const void *lmbda_t,
+                      double gamma, double lmbda, int rolling_gamma, int64_t O, int64_t T, int64_t I,
+                      void *returns, int algo) {
+    if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td_lambda_fwd: bad dtype");
+    if (int rc = check_dims("trl_td_lambda_fwd", O, T, I)) return rc;
+    if (!reward || !next_state_value || !done || !terminated || !returns)
+        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td_lambda_fwd: null tensor pointer");
+    if (!rolling_gamma && !gamma_t && !lmbda_t)
+        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td_lambda_fwd: rolling_gamma=0 needs a gamma or lmbda tensor");
+    TdLambdaArgs a{reward, next_state_value, done, terminated, gamma_t, lmbda_t, gamma, lmbda, O, T, I, returns};
+    hipStream_t s = (hipStream_t)stream;
+    LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
+    if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ)
+        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td_lambda_fwd: unknown algo %d", algo);
+    if (rolling_gamma && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN)) res = launch_td_lambda_scan(s, val_dtype, coef_dtype, a);
+    if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
+        return fail(TRL_ERR_UNSUPPORTED, "trl_td_lambda_fwd: SCAN family does not support this case (needs I == 1, rolling gamma)");
+    if (res.status == TRL_ERR_UNSUPPORTED) res = launch_td_lambda_seq(s, val_dtype, coef_dtype, a, rolling_gamma);
+    if (res.status != 0) return fail(res.status, "trl_td_lambda_fwd: launch rejected (grid too large?)");
+    if (int rc = check_launch("trl_td_lambda_fwd")) return rc;
+    g_kernel = res.kernel;
+    return TRL_OK;
+}
+
+int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_pi, const void *log_mu,
+                   const void *state_value, const void *next_state_value, const void *reward,
+                   const uint8_t *done, const uint8_t *terminated, const void *gamma_t, double gamma,
+                   double rho_thresh, double c_thresh, int64_t O, int64_t T, int64_t I,
+                   void *advantage, void *vs, int algo) {
+    if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_fwd: bad dtype");
+    if (int rc = check_dims("trl_vtrace_fwd", O, T, I)) return rc;
+    if (!log_pi || !log_mu || !state_value || !next_state_value || !reward || !done || !terminated || !advantage || !vs)
+        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_fwd: null tensor pointer");
+    VtraceArgs a{log_pi, log_mu, state_value, next_state_value, reward, done, terminated, gamma_t,
+                 gamma, rho_thresh, c_thresh, O, T, I, advantage, vs};
+    hipStream_t s = (hipStream_t)stream;
+    LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
+    if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ)
+        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_fwd: unknown algo %d", algo);
+    if (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN) res = launch_vtrace_scan(s, val_dtype, coef_dtype, a);
+    if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
+        return fail(TRL_ERR_UNSUPPORTED, "trl_vtrace_fwd: SCAN family does not support this shape (needs I == 1)");
+    if (res.status == TRL_ERR_UNSUPPORTED) res = launch_vtrace_seq(s, val_dtype, coef_dtype, a);
+    if (res.status != 0) return fail(res.status, "trl_vtrace_fwd: launch rejected (grid too large?)");
+    if (int rc = check_launch("trl_vtrace_fwd")) return rc;
+    g_kernel = res.kernel;
+    return TRL_OK;
+}
+
+int trl_normalize(void *stream, int dtype, const void *x, int64_t n, const double *stats, double eps, void *out) {
+    if (!dtype_ok(dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_normalize: bad dtype");
+    if (n <= 0 || !x || !out || !stats) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_normalize: null pointer or n <= 0");
+    launch_normalize((hipStream_t)stream, dtype, x, n, stats, eps, out);
+    if (int rc = check_launch("trl_normalize")) return rc;
+    g_kernel = "normalize";
+    return TRL_OK;
+}
+
+int trl_moments(void *stream, int dtype, const void *x, int64_t n, double *stats, void *workspace, size_t workspace_bytes) {
+    if (!dtype_ok(dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_moments: bad dtype");
+    if (n <= 0 || !x || !stats) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_moments: null pointer or n <= 0");
+    if (!workspace || workspace_bytes < trl_workspace_bytes(n, 1, 1) || ((uintptr_t)workspace & 7))
+        return fail(TRL_ERR_WORKSPACE, "trl_moments: workspace is %zu bytes, need %zu (8-byte aligned)", workspace_bytes,
+                    trl_workspace_bytes(n, 1, 1));
+    i64 np = 0;
+    launch_moments((hipStream_t)stream, dtype, x, n, (double *)workspace, &np);
+    if (int rc = check_launch("trl_moments")) return rc;
+    launch_reduce_partials((hipStream_t)stream, (const double *)workspace, np, (double)n, stats);
+    if (int rc = check_launch("trl_moments(reduce)")) return rc;
+    g_kernel = "moments";
+    return TRL_OK;
+}
+
+}  // extern "C"

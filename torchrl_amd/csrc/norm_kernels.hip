@@ -1,0 +1,126 @@
+// Advantage statistics and normalisation.
+// Replaces `(adv - adv.mean()) / adv.std().clamp_min(eps)` (reference:
+// torchrl/objectives/value/advantages.py:1459-1463, 1828-1832; torchrl/_utils.py:901-912).
+//
+// Statistics travel as {N, sum, sumsq} in fp64 so that a batch sharded over GPUs needs one
+// 24-byte all-reduce.  All reductions run in a fixed order (per-lane strided accumulation ->
+// wave shuffle tree -> per-block partial -> single-block final tree): bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+constexpr int kRedThreads = 256;
+
+// Final reduction of per-block {sum, sumsq} partials into stats = {N, sum, sumsq}.
+__global__ __launch_bounds__(kRedThreads) void reduce_partials_kernel(const double *__restrict__ partials,
+                                                                      i64 npartials, double n,
+                                                                      double *__restrict__ stats) {
+    __shared__ double red[2 * kRedThreads / kWave];
+    double s = 0.0, ss = 0.0;
+    for (i64 k = threadIdx.x; k < npartials; k += kRedThreads) {
+        s += partials[2 * k];
+        ss += partials[2 * k + 1];
+    }
+    block_sum2<kRedThreads>(s, ss, red);
+    if (threadIdx.x == 0) {
+        stats[0] = n;
+        stats[1] = s;
+        stats[2] = ss;
+    }
+}
+
+template <typename TS>
+__global__ __launch_bounds__(kRedThreads) void moments_kernel(const TS *__restrict__ x, i64 n,
+                                                              double *__restrict__ partials) {
+    __shared__ double red[2 * kRedThreads / kWave];
+    double s = 0.0, ss = 0.0;
+    const i64 stride = (i64)gridDim.x * kRedThreads;
+    for (i64 k = (i64)blockIdx.x * kRedThreads + threadIdx.x; k < n; k += stride) {
+        const double xv = (double)x[k];
+        s += xv;
+        ss += xv * xv;
+    }
+    block_sum2<kRedThreads>(s, ss, red);
+    if (threadIdx.x == 0) {
+        partials[2 * (i64)blockIdx.x] = s;
+        partials[2 * (i64)blockIdx.x + 1] = ss;
+    }
+}
+
+template <typename TS>
+struct Vec4 { TS x, y, z, w; };
+
+// mean / clamped std in the storage dtype, from {N, sum, sumsq}.
+template <typename TS>
+__device__ __forceinline__ void mean_std(const double *__restrict__ stats, double eps, TS &mean_s, TS &std_s) {
+    const double n = stats[0], s = stats[1], ss = stats[2];
+    const double mean = s / n;
+    double var = (ss - n * mean * mean) / (n - 1.0);  // unbiased, as torch.std
+    if (var < 0.0) var = 0.0;                         // rounding only; NaN (n == 1) stays NaN
+    mean_s = (TS)mean;
+    std_s = (TS)sqrt(var);
+    const TS eps_s = (TS)eps;
+    if (std_s < eps_s) std_s = eps_s;                 // clamp_min keeps NaN
+}
+
+template <typename TS>
+__global__ __launch_bounds__(kRedThreads) void normalize_kernel(const TS *__restrict__ x, i64 n,
+                                                                const double *__restrict__ stats, double eps,
+                                                                TS *__restrict__ out, int vec_ok) {
+    TS mean_s, std_s;
+    mean_std<TS>(stats, eps, mean_s, std_s);
+    const i64 stride = (i64)gridDim.x * kRedThreads;
+    const i64 tid = (i64)blockIdx.x * kRedThreads + threadIdx.x;
+    if (vec_ok) {
+        constexpr int V = 16 / sizeof(TS);
+        typedef TS vec_t __attribute__((ext_vector_type(V)));
+        const i64 nv = n / V;
+        const vec_t *__restrict__ xv = (const vec_t *)x;
+        vec_t *__restrict__ ov = (vec_t *)out;
+        for (i64 k = tid; k < nv; k += stride) {
+            vec_t a = xv[k];
+#pragma unroll
+            for (int e = 0; e < V; ++e) a[e] = (a[e] - mean_s) / std_s;
+            ov[k] = a;
+        }
+        for (i64 k = nv * V + tid; k < n; k += stride) out[k] = (x[k] - mean_s) / std_s;
+    } else {
+        for (i64 k = tid; k < n; k += stride) out[k] = (x[k] - mean_s) / std_s;
+    }
+}
+
+inline i64 stream_blocks(i64 n, int per_thread) {
+    i64 nb = (n + (i64)kRedThreads * per_thread - 1) / ((i64)kRedThreads * per_thread);
+    if (nb < 1) nb = 1;
+    if (nb > 2048) nb = 2048;  // 256 CUs x 8 blocks; grid-stride the rest
+    return nb;
+}
+
+}  // namespace
+
+int launch_reduce_partials(hipStream_t s, const double *partials, i64 npartials, double n, double *stats) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kRedThreads), 0, s, partials, npartials, n, stats);
+    return 0;
+}
+
+i64 moments_max_partials(i64 n) { return stream_blocks(n, 4); }
+
+int launch_moments(hipStream_t s, int dt, const void *x, i64 n, double *partials, i64 *npartials) {
+    const i64 nb = stream_blocks(n, 4);
+    if (dt == 0)
+        hipLaunchKernelGGL((moments_kernel<float>), dim3((unsigned)nb), dim3(kRedThreads), 0, s, (const float *)x, n, partials);
+    else
+        hipLaunchKernelGGL((moments_kernel<double>), dim3((unsigned)nb), dim3(kRedThreads), 0, s, (const double *)x, n, partials);
+    *npartials = nb;
+    return 0;
+}
+
+int launch_normalize(hipStream_t s, int dt, const void *x, i64 n, const double *stats, double eps, void *out) {
+    const int vec_ok = (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
+    const i64 nb = stream_blocks(n, dt == 0 ? 4 : 2);
+    if (dt == 0)
+        hipLaunchKernelGGL((normalize_kernel<float>), dim3((unsigned)nb), dim3(kRedThreads), 0, s, (const float *)x, n, stats, eps, (float *)out, vec_ok);
+    else
+        hipLaunchKernelGGL((normalize_kernel<double>), dim3((unsigned)nb), dim3(kRedThreads), 0, s, (const double *)x, n, stats, eps, (double *)out, vec_ok);
+    return 0;
+}

@@ -1,0 +1,862 @@
+"""MI355X-native functional value estimators.
+
+Drop-in for ``torchrl.objectives.value.functional`` (reference:
+torchrl/objectives/value/functional.py): same names, argument order, keyword-only
+``time_dim`` where the reference has it, same ``done`` / ``terminated`` semantics, same
+``[*B, T, *F]`` conventions and the same exceptions.  Everything below the Python signature
+is replaced by one call into the HIP library (include/trl_value.h); there is no PyTorch or
+CPU fallback -- a CPU tensor or a missing library raises.
+
+Host-side work done here (and only here):
+  * shape / time-dim validation with the reference's error types and messages
+    (functional.py:44-46, 49-113);
+  * canonicalisation to the contiguous ``(O, T, I)`` view the kernels use -- directly from
+    the original layout, so a contiguous ``[*B, T, *F]`` input is never copied or transposed
+    whatever ``time_dim`` is (the reference's ``_transpose_time`` would hand non-contiguous
+    views to ATen);
+  * reproducing the dtype / rounding of the reference's coefficient tensors
+    (``gamma * int_mask`` rounds python floats to the default dtype even for float64 values,
+    functional.py:172-174, 1322-1323; ``torch.full_like(next_state_value, gamma)`` keeps the
+    value dtype, functional.py:850-857) so that the kernels receive already-rounded scalars.
+
+The ``vec_*`` variants call the same kernels: the scan is exact, so the reference's truncated
+geometric filter (functional.py:185-210) and its O(T^2) gamma tables (value/utils.py:131-182)
+have no counterpart here.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import warnings
+from dataclasses import dataclass
+from functools import wraps
+from typing import Optional, Tuple, Union
+
+import torch
+
+from torchrl_amd import _extension
+
+__all__ = [
+    "generalized_advantage_estimate",
+    "vec_generalized_advantage_estimate",
+    "td0_advantage_estimate",
+    "td0_return_estimate",
+    "td1_return_estimate",
+    "vec_td1_return_estimate",
+    "td1_advantage_estimate",
+    "vec_td1_advantage_estimate",
+    "td_lambda_return_estimate",
+    "vec_td_lambda_return_estimate",
+    "td_lambda_advantage_estimate",
+    "vec_td_lambda_advantage_estimate",
+    "vtrace_advantage_estimate",
+    "reward2go",
+]
+
+SHAPE_ERR = "All input tensors (value, reward and done states) must share a unique shape."
+_TIME_ERR = "The tensor shape and the time dimension are not compatible: got {} and time_dim={}."
+
+ALGO_AUTO, ALGO_SEQ, ALGO_SCAN = 0, 1, 2
+_DT = {torch.float32: 0, torch.float64: 1}
+
+
+# ---------------------------------------------------------------------------------------------
+# time-dim handling
+# ---------------------------------------------------------------------------------------------
+def _transpose_time(fun):
+    """Same contract as the reference decorator (functional.py:49-113): pops the ``time_dim``
+    keyword, brings time to dim -2 on every tensor argument with more than one element, and
+    transposes the outputs back.  Used by the estimators that are plain torch compositions
+    (``td0``/``td1``/``reward2go`` rows); the kernel-backed estimators canonicalise directly."""
+
+    @wraps(fun)
+    def transposed_fun(*args, **kwargs):
+        time_dim = kwargs.pop("time_dim", -2)
+
+        def transpose_tensor(tensor):
+            if not isinstance(tensor, torch.Tensor) or tensor.numel() <= 1:
+                return tensor, False
+            timedim = time_dim - tensor.ndim if time_dim >= 0 else time_dim
+            if timedim < -tensor.ndim or timedim >= 0:
+                raise RuntimeError(_TIME_ERR.format(tensor.shape, timedim))
+            if tensor.ndim >= 2:
+                return tensor.transpose(timedim, -2), False
+            if tensor.ndim == 1 and timedim == -1:
+                return tensor.unsqueeze(-1), True
+            raise RuntimeError(_TIME_ERR.format(tensor.shape, timedim))
+
+        if time_dim != -2:
+            single_dim = False
+            if args:
+                args, sd = zip(*(transpose_tensor(arg) for arg in args))
+                single_dim = any(sd)
+            for k, item in list(kwargs.items()):
+                item, sd = transpose_tensor(item)
+                single_dim = single_dim or sd
+                kwargs[k] = item
+            out = fun(*args, **kwargs)
+            if isinstance(out, torch.Tensor):
+                out = transpose_tensor(out)[0]
+                return out.squeeze(-2) if single_dim else out
+            if single_dim:
+                return tuple(transpose_tensor(_out)[0].squeeze(-2) for _out in out)
+            return tuple(transpose_tensor(_out)[0] for _out in out)
+        out = fun(*args, **kwargs)
+        for _out in out if isinstance(out, tuple) else (out,):
+            if _out.ndim < 2:
+                raise RuntimeError(_TIME_ERR.format(_out.shape, time_dim))
+        return out
+
+    return transposed_fun
+
+
+def _canonical_dims(shape, time_dim: int) -> Tuple[int, int, int, int]:
+    """``(O, T, I, td)`` for a ``[*B, T, *F]`` tensor with time at ``time_dim``; ``td`` is the
+    non-negative index of the time dim.  Raises the reference's time-dim ``RuntimeError``."""
+    nd = len(shape)
+    td = time_dim - nd if time_dim >= 0 else time_dim
+    if td < -nd or td >= 0:
+        raise RuntimeError(_TIME_ERR.format(torch.Size(shape), td))
+    if nd == 1:
+        if td != -1:
+            raise RuntimeError(_TIME_ERR.format(torch.Size(shape), td))
+        return 1, int(shape[0]), 1, 0
+    td += nd
+    return math.prod(shape[:td]), int(shape[td]), math.prod(shape[td + 1 :]), td
+
+
+def _expand_coef(x: torch.Tensor, shape, time_dim: int) -> torch.Tensor:
+    """Broadcast a coefficient tensor (numel > 1) to ``shape`` the way the reference does:
+    the decorator transposes it like every other tensor, then it broadcasts against the
+    transposed operands (functional.py:64-91, 172-174)."""
+    nd = len(shape)
+    if tuple(x.shape) == tuple(shape):
+        return x
+    td = time_dim - nd if time_dim >= 0 else time_dim
+    if td == -2 or nd < 2:
+        return x.expand(shape)
+    xtd = time_dim - x.ndim if time_dim >= 0 else time_dim
+    if xtd < -x.ndim or xtd >= 0 or x.ndim < 2:
+        raise RuntimeError(_TIME_ERR.format(x.shape, xtd))
+    tshape = list(shape)
+    tshape[td], tshape[-2] = tshape[-2], tshape[td]
+    return x.transpose(xtd, -2).expand(tshape).transpose(td, -2)
+
+
+# ---------------------------------------------------------------------------------------------
+# coefficient rounding
+# ---------------------------------------------------------------------------------------------
+def _round_to(value: float, dtype: torch.dtype) -> float:
+    if dtype == torch.float64:
+        return float(value)
+    return float(torch.tensor(value, dtype=dtype))
+
+
+def _is_full(x) -> bool:
+    return isinstance(x, torch.Tensor) and x.numel() > 1
+
+
+def _mask_coef_dtype(x) -> torch.dtype:
+    """dtype of ``x * int32_mask`` for scalar-like or tensor x."""
+    if isinstance(x, torch.Tensor) and x.dtype.is_floating_point:
+        return x.dtype
+    return torch.get_default_dtype()
+
+
+def _scalar_mask_coef(x) -> Tuple[float, torch.dtype]:
+    """value and dtype of ``x * int32_mask`` where the mask is 1, for scalar-like x
+    (python number, 0-dim or 1-element tensor)."""
+    dt = _mask_coef_dtype(x)
+    if isinstance(x, torch.Tensor):
+        val = float(x)  # host read; device scalars synchronise (modules cache host copies)
+        return (val if x.dtype.is_floating_point else _round_to(val, dt)), dt
+    return _round_to(float(x), dt), dt
+
+
+# ---------------------------------------------------------------------------------------------
+# tensor plumbing
+# ---------------------------------------------------------------------------------------------
+def _check_value_dtype(*tensors) -> torch.dtype:
+    dt = tensors[0].dtype
+    for t in tensors[1:]:
+        dt = torch.promote_types(dt, t.dtype)
+    if dt not in _DT:
+        raise NotImplementedError(
+            f"torchrl_amd value estimators support float32 and float64 tensors, got {dt}"
+        )
+    return dt
+
+
+def _require_hip(t: torch.Tensor):
+    if t.device.type != "cuda":
+        raise RuntimeError(
+            "torchrl_amd value estimators run on MI355X (HIP, device type 'cuda') tensors only; "
+            f"got a tensor on {t.device}. There is no CPU fallback."
+        )
+
+
+def _val(t: torch.Tensor, dtype, device=None) -> torch.Tensor:
+    t = t.detach()
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    if device is not None and t.device != device:
+        t = t.to(device)
+    return t.contiguous()
+
+
+def _mask(m: torch.Tensor, shape, device=None) -> torch.Tensor:
+    m = m.detach()
+    if m.dtype != torch.bool:
+        m = m != 0
+    if tuple(m.shape) != tuple(shape):
+        m = m.expand(shape)
+    if device is not None and m.device != device:
+        m = m.to(device)
+    return m.contiguous().view(torch.uint8)  # materialises stride-0 expanded masks (DoneTransform)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _needs_grad(*xs) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(x, torch.Tensor) and x.requires_grad for x in xs)
+
+
+_GRAD_MSG = (
+    "torchrl_amd: differentiating through {} is not implemented yet (forward HIP kernels only); "
+    "call it under torch.no_grad() / with differentiable=False, or detach the inputs."
+)
+
+
+def last_kernel() -> str:
+    """Name of the kernel family the last call on this thread dispatched to (for tests / profiling)."""
+    return _extension.get_lib().trl_last_kernel().decode()
+
+
+# ---------------------------------------------------------------------------------------------
+# GAE
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class _GaeCall:
+    shape: tuple
+    O: int
+    T: int
+    I: int
+    vdt: torch.dtype
+    cdt: torch.dtype
+    out_dtype: torch.dtype
+    reward: torch.Tensor
+    value: torch.Tensor
+    next_value: torch.Tensor
+    done: torch.Tensor
+    terminated: torch.Tensor
+    gamma_t: Optional[torch.Tensor]
+    lg_t: Optional[torch.Tensor]
+    gamma: float
+    lmbda: float
+    lg: float
+
+
+def _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim) -> _GaeCall:
+    """Host logic of the GAE entry points: validation, canonical view, coefficient rounding."""
+    if terminated is None:
+        terminated = done  # reference clones; the kernels never write their inputs
+    if not (next_state_value.shape == state_value.shape == reward.shape == done.shape == terminated.shape):
+        raise RuntimeError(SHAPE_ERR)
+    shape = tuple(next_state_value.shape)
+    O, T, I, _ = _canonical_dims(shape, time_dim)
+    vdt = _check_value_dtype(reward, state_value, next_state_value)
+    dev = next_state_value.device
+
+    gamma_t = lg_t = None
+    g_val = l_val = lg_val = 0.0
+    if _is_full(gamma) or _is_full(lmbda):
+        if _is_full(gamma) and not _is_full(lmbda):
+            # lg = (coef)lmbda * gamma_t is formed in-kernel (what `lmbda * gamma` gives)
+            cdt = _mask_coef_dtype(gamma)
+            gamma_t = _expand_coef(gamma.detach(), shape, time_dim).to(device=dev, dtype=cdt).contiguous()
+            l_val = float(lmbda)
+        else:
+            prod = lmbda * (gamma.detach() if isinstance(gamma, torch.Tensor) else gamma)
+            g_full = gamma.detach() if _is_full(gamma) else torch.full((), float(gamma), dtype=_mask_coef_dtype(gamma))
+            cdt = torch.promote_types(_mask_coef_dtype(g_full), _mask_coef_dtype(prod))
+            lg_t = _expand_coef(prod.detach(), shape, time_dim).to(device=dev, dtype=cdt).contiguous()
+            gamma_t = (_expand_coef(g_full, shape, time_dim) if g_full.numel() > 1 else g_full.expand(shape)).to(
+                device=dev, dtype=cdt).contiguous()
+    else:
+        g_val, g_dt = _scalar_mask_coef(gamma)
+        lg_val, lg_dt = _scalar_mask_coef(lmbda * gamma)
+        cdt = torch.promote_types(g_dt, lg_dt)
+    if cdt not in _DT:
+        raise NotImplementedError(f"gamma / lmbda dtype {cdt} is not supported (float32 / float64 only)")
+    return _GaeCall(
+        shape=shape, O=O, T=T, I=I, vdt=vdt, cdt=cdt, out_dtype=next_state_value.dtype,
+        reward=_val(reward, vdt, dev), value=_val(state_value, vdt, dev), next_value=_val(next_state_value, vdt, dev),
+        done=_mask(done, shape, dev), terminated=_mask(terminated, shape, dev),
+        gamma_t=gamma_t, lg_t=lg_t, gamma=g_val, lmbda=l_val, lg=lg_val,
+    )
+
+
+def _launch_gae(c: _GaeCall, want_stats: bool = False, algo: int = ALGO_AUTO):
+    lib = _extension.get_lib()
+    _require_hip(c.next_value)
+    dev = c.next_value.device
+    adv = torch.empty(c.shape, dtype=c.vdt, device=dev)
+    vt = torch.empty(c.shape, dtype=c.vdt, device=dev)
+    stats = ws = None
+    ws_bytes = 0
+    if want_stats:
+        ws_bytes = lib.trl_workspace_bytes(c.O, c.T, c.I)
+        ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.float64, device=dev)
+        stats = torch.empty(3, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.trl_gae_fwd(
+            _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.value), _ptr(c.next_value),
+            _ptr(c.done), _ptr(c.terminated), _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg,
+            c.O, c.T, c.I, _ptr(adv), _ptr(vt), _ptr(stats), _ptr(ws), ws_bytes, algo)
+    _extension.check(rc, lib)
+    if c.out_dtype != c.vdt:
+        adv, vt = adv.to(c.out_dtype), vt.to(c.out_dtype)
+    return adv, vt, stats
+
+
+def generalized_advantage_estimate(
+    gamma: float,
+    lmbda: float,
+    state_value: torch.Tensor,
+    next_state_value: torch.Tensor,
+    reward: torch.Tensor,
+    done: torch.Tensor,
+    terminated: torch.Tensor | None = None,
+    *,
+    time_dim: int = -2,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Generalized advantage estimate of a trajectory (reference: functional.py:121-182).
+
+    Returns ``(advantage, value_target)``.  All tensors must have shape
+    ``[*Batch x TimeSteps x *F]``; ``terminated`` defaults to ``done``.
+    """
+    if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
+        raise NotImplementedError(_GRAD_MSG.format("generalized_advantage_estimate"))
+    call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
+    adv, vt, _ = _launch_gae(call)
+    return adv, vt
+
+
+def vec_generalized_advantage_estimate(
+    gamma: Union[float, torch.Tensor],
+    lmbda: Union[float, torch.Tensor],
+    state_value: torch.Tensor,
+    next_state_value: torch.Tensor,
+    reward: torch.Tensor,
+    done: torch.Tensor,
+    terminated: torch.Tensor | None = None,
+    *,
+    time_dim: int = -2,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Vectorized GAE (reference: functional.py:272-370).  Same kernels as the loop variant:
+    the result is exact rather than filter-truncated."""
+    if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
+        raise NotImplementedError(_GRAD_MSG.format("vec_generalized_advantage_estimate"))
+    call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
+    call.out_dtype = state_value.dtype  # functional.py:314
+    adv, vt, _ = _launch_gae(call)
+    return adv, vt
+
+
+def gae_with_stats(gamma, lmbda, state_value, next_state_value, reward, done, terminated=None, *, time_dim=-2,
+                   algo: int = ALGO_AUTO):
+    """GAE plus the fp64 moments ``{N, sum(A), sum(A^2)}`` of the advantage (device tensor of 3
+    doubles), produced by the same launch sequence; feeds :func:`normalize_` (after an
+    all-reduce when the batch is sharded).  No reference counterpart: the reference computes
+    ``adv.mean()`` / ``adv.std()`` as separate passes (advantages.py:1459-1463)."""
+    call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
+    return _launch_gae(call, want_stats=True, algo=algo)
+
+
+# ---------------------------------------------------------------------------------------------
+# normalisation
+# ---------------------------------------------------------------------------------------------
+def moments(x: torch.Tensor) -> torch.Tensor:
+    """``{N, sum, sumsq}`` of ``x`` in fp64 (device tensor of 3 doubles)."""
+    lib = _extension.get_lib()
+    _require_hip(x)
+    xc = x.detach().contiguous()
+    if xc.dtype not in _DT:
+        raise NotImplementedError(f"moments: dtype {xc.dtype} unsupported")
+    n = xc.numel()
+    ws_bytes = lib.trl_workspace_bytes(n, 1, 1)
+    ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.float64, device=x.device)
+    stats = torch.empty(3, dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.trl_moments(_stream(x.device), _DT[xc.dtype], _ptr(xc), n, _ptr(stats), _ptr(ws), ws_bytes)
+    _extension.check(rc, lib)
+    return stats
+
+
+def normalize_(x: torch.Tensor, stats: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``(x - mean) / std.clamp_min(eps)`` with mean / unbiased std taken from ``stats``
+    (reference: advantages.py:1459-1463).  In place unless ``out`` is given."""
+    lib = _extension.get_lib()
+    _require_hip(x)
+    if not x.is_contiguous() or x.dtype not in _DT:
+        raise ValueError("normalize_: x must be a contiguous float32/float64 tensor")
+    if stats.dtype != torch.float64 or stats.numel() != 3 or stats.device != x.device:
+        raise ValueError("normalize_: stats must be 3 float64 values on x's device")
+    out = x if out is None else out
+    if out.shape != x.shape or out.dtype != x.dtype or not out.is_contiguous():
+        raise ValueError("normalize_: out must match x")
+    with torch.cuda.device(x.device):
+        rc = lib.trl_normalize(_stream(x.device), _DT[x.dtype], _ptr(x), x.numel(), _ptr(stats), float(eps), _ptr(out))
+    _extension.check(rc, lib)
+    return out
+
+
+def standardize(x: torch.Tensor, eps: float, group=None, distributed: bool = False) -> torch.Tensor:
+    """Out-of-place ``(x - mean) / std.clamp_min(eps)`` over all elements.  With ``distributed``
+    (or an explicit process ``group``) the fp64 moments are all-reduced first -- one 24-byte RCCL
+    all-reduce -- so every rank normalises with the global statistics of the sharded batch."""
+    xc = x.detach().contiguous()
+    st = moments(xc)
+    if (distributed or group is not None) and torch.distributed.is_initialized():
+        if torch.distributed.get_world_size(group) > 1:
+            torch.distributed.all_reduce(st, group=group)
+    return normalize_(xc, st, eps, out=torch.empty_like(xc))
+
+
+# ---------------------------------------------------------------------------------------------
+# TD(lambda)
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class _TdLambdaCall:
+    shape: tuple
+    O: int
+    T: int
+    I: int
+    vdt: torch.dtype
+    cdt: torch.dtype
+    reward: torch.Tensor
+    next_value: torch.Tensor
+    done: torch.Tensor
+    terminated: torch.Tensor
+    gamma_t: Optional[torch.Tensor]
+    lmbda_t: Optional[torch.Tensor]
+    gamma: float
+    lmbda: float
+    rolling: bool
+
+
+def _td_coef(x, done_shape, vdt, name):
+    """gamma / lmbda of TD(lambda): a tensor of the inputs' shape is per-element, anything else
+    goes through ``torch.full_like(next_state_value, x)`` (functional.py:850-857)."""
+    if isinstance(x, torch.Tensor) and tuple(x.shape) == tuple(done_shape):
+        return x.detach(), 0.0, (x.dtype if x.dtype.is_floating_point else vdt)
+    if isinstance(x, torch.Tensor):
+        if x.numel() != 1:
+            raise RuntimeError(
+                f"{name} must be a scalar or a tensor with the shape of the inputs {tuple(done_shape)}, got {tuple(x.shape)}")
+        x = float(x)
+    return None, _round_to(float(x), vdt), vdt
+
+
+def _prepare_td_lambda(gamma, lmbda, next_state_value, reward, done, terminated, rolling_gamma, time_dim,
+                       vec: bool = False) -> _TdLambdaCall:
+    if terminated is None:
+        terminated = done
+    if not (next_state_value.shape == reward.shape == done.shape == terminated.shape):
+        raise RuntimeError(SHAPE_ERR)
+    shape = tuple(next_state_value.shape)
+    O, T, I, _ = _canonical_dims(shape, time_dim)
+    vdt = _check_value_dtype(reward, next_state_value)
+    dev = next_state_value.device
+    if vec:
+        # the vec variant broadcasts gamma / lmbda tensors ([B, T, 1] documented, functional.py:1045-1047)
+        if _is_full(gamma) and tuple(gamma.shape) != shape:
+            gamma = _expand_coef(gamma, shape, time_dim)
+        if _is_full(lmbda) and tuple(lmbda.shape) != shape:
+            lmbda = _expand_coef(lmbda, shape, time_dim)
+    g_t, g_val, g_dt = _td_coef(gamma, shape, vdt, "gamma")
+    l_t, l_val, l_dt = _td_coef(lmbda, shape, vdt, "lmbda")
+    if rolling_gamma is None:
+        rolling_gamma = True
+    elif not rolling_gamma and g_t is None and l_t is None:
+        raise RuntimeError("rolling_gamma=False is expected only with time-sensitive gamma or lambda values")
+    cdt = torch.promote_types(g_dt, l_dt)
+    if cdt not in _DT:
+        raise NotImplementedError(f"gamma / lmbda dtype {cdt} is not supported (float32 / float64 only)")
+    if g_t is not None:
+        g_t = g_t.to(device=dev, dtype=cdt).contiguous()
+    if l_t is not None:
+        l_t = l_t.to(device=dev, dtype=cdt).contiguous()
+    return _TdLambdaCall(shape=shape, O=O, T=T, I=I, vdt=vdt, cdt=cdt, reward=_val(reward, vdt, dev),
+                         next_value=_val(next_state_value, vdt, dev), done=_mask(done, shape, dev),
+                         terminated=_mask(terminated, shape, dev), gamma_t=g_t, lmbda_t=l_t, gamma=g_val,
+                         lmbda=l_val, rolling=bool(rolling_gamma))
+
+
+def _launch_td_lambda(c: _TdLambdaCall, out_dtype, algo: int = ALGO_AUTO) -> torch.Tensor:
+    lib = _extension.get_lib()
+    _require_hip(c.next_value)
+    dev = c.next_value.device
+    out = torch.empty(c.shape, dtype=c.vdt, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.trl_td_lambda_fwd(
+            _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.next_value), _ptr(c.done), _ptr(c.terminated),
+            _ptr(c.gamma_t), _ptr(c.lmbda_t), c.gamma, c.lmbda, 1 if c.rolling else 0, c.O, c.T, c.I, _ptr(out), algo)
+    _extension.check(rc, lib)
+    return out if out_dtype == c.vdt else out.to(out_dtype)
+
+
+def td_lambda_return_estimate(
+    gamma: float,
+    lmbda: float,
+    next_state_value: torch.Tensor,
+    reward: torch.Tensor,
+    done: torch.Tensor,
+    terminated: torch.Tensor | None = None,
+    rolling_gamma: bool = None,
+    *,
+    time_dim: int = -2,
+) -> torch.Tensor:
+    r"""TD(:math:`\lambda`) return estimate (reference: functional.py:783-889).
+
+    ``gamma`` / ``lmbda`` may be scalars or tensors with the shape of the inputs.
+    ``rolling_gamma=False`` (each return uses the gamma / lmbda of its own first step for the
+    whole tail) runs the O(T^2) kernel and needs a gamma or lmbda tensor.
+    """
+    if _needs_grad(next_state_value, reward, gamma, lmbda):
+        raise NotImplementedError(_GRAD_MSG.format("td_lambda_return_estimate"))
+    call = _prepare_td_lambda(gamma, lmbda, next_state_value, reward, done, terminated, rolling_gamma, time_dim)
+    return _launch_td_lambda(call, next_state_value.dtype)
+
+
+def vec_td_lambda_return_estimate(
+    gamma,
+    lmbda,
+    next_state_value,
+    reward,
+    done,
+    terminated: torch.Tensor | None = None,
+    rolling_gamma: Optional[bool] = None,
+    *,
+    time_dim: int = -2,
+):
+    r"""Vectorized TD(:math:`\lambda`) return estimate (reference: functional.py:1030-1183).
+    Same kernels as the loop variant; keeps the reference's ``NotImplementedError`` for
+    ``rolling_gamma=False`` with tensor coefficients."""
+    if terminated is None:
+        terminated = done
+    if not (next_state_value.shape == reward.shape == done.shape == terminated.shape):
+        raise RuntimeError(SHAPE_ERR)
+    if _needs_grad(next_state_value, reward, gamma, lmbda):
+        raise NotImplementedError(_GRAD_MSG.format("vec_td_lambda_return_estimate"))
+
+    def _is_scalar(t):
+        return not isinstance(t, torch.Tensor) or t.numel() == 1
+
+    if not (_is_scalar(gamma) and _is_scalar(lmbda)) and rolling_gamma is not None and not rolling_gamma:
+        _, _, _, td = _canonical_dims(tuple(done.shape), time_dim)
+        term = terminated.movedim(td, 0) if terminated.ndim > 1 else terminated
+        terminated_follows_terminated = term[1:][term[:-1]].all()
+        if not terminated_follows_terminated:
+            raise NotImplementedError(
+                "When using rolling_gamma=False and vectorized TD(lambda) with time-dependent gamma, "
+                "make sure that conseducitve trajectories are separated as different batch "
+                "items. Propagating a gamma value across trajectories is not permitted with "
+                "this method. Check that you need to use rolling_gamma=False, and if so "
+                "consider using the non-vectorized version of the return computation or splitting "
+                "your trajectories."
+            )
+        raise NotImplementedError(
+            "The vectorized version of TD(lambda) with rolling_gamma=False is currently not available. "
+            "To use this feature, use the non-vectorized version of TD(lambda). You can expect "
+            "good speed improvements by decorating the function with torch.compile!"
+        )
+    if _is_scalar(gamma) and _is_scalar(lmbda):
+        rolling_gamma = None  # the reference's fast path ignores it (functional.py:1101-1110)
+    call = _prepare_td_lambda(gamma, lmbda, next_state_value, reward, done, terminated, rolling_gamma, time_dim, vec=True)
+    return _launch_td_lambda(call, next_state_value.dtype)
+
+
+def _check5(state_value, next_state_value, reward, done, terminated):
+    if not (next_state_value.shape == state_value.shape == reward.shape == done.shape == terminated.shape):
+        raise RuntimeError(SHAPE_ERR)
+
+
+def td_lambda_advantage_estimate(
+    gamma: float,
+    lmbda: float,
+    state_value: torch.Tensor,
+    next_state_value: torch.Tensor,
+    reward: torch.Tensor,
+    done: torch.Tensor,
+    terminated: torch.Tensor | None = None,
+    rolling_gamma: bool = None,
+    # not a kwarg because used directly
+    time_dim: int = -2,
+) -> torch.Tensor:
+    r"""TD(:math:`\lambda`) advantage estimate (reference: functional.py:892-969)."""
+    if terminated is None:
+        terminated = done
+    _check5(state_value, next_state_value, reward, done, terminated)
+    returns = td_lambda_return_estimate(gamma, lmbda, next_state_value, reward, done, terminated=terminated,
+                                        rolling_gamma=rolling_gamma, time_dim=time_dim)
+    return returns - state_value
+
+
+def vec_td_lambda_advantage_estimate(
+    gamma,
+    lmbda,
+    state_value,
+    next_state_value,
+    reward,
+    done,
+    terminated: torch.Tensor | None = None,
+    rolling_gamma: bool = None,
+    # not a kwarg because used directly
+    time_dim: int = -2,
+):
+    r"""Vectorized TD(:math:`\lambda`) advantage estimate (reference: functional.py:1186-1262)."""
+    if terminated is None:
+        terminated = done
+    _check5(state_value, next_state_value, reward, done, terminated)
+    return vec_td_lambda_return_estimate(gamma, lmbda, next_state_value, reward, done=done, terminated=terminated,
+                                         rolling_gamma=rolling_gamma, time_dim=time_dim) - state_value
+
+
+# ---------------------------------------------------------------------------------------------
+# V-trace
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class _VtraceCall:
+    shape: tuple
+    O: int
+    T: int
+    I: int
+    vdt: torch.dtype
+    cdt: torch.dtype
+    log_pi: torch.Tensor
+    log_mu: torch.Tensor
+    value: torch.Tensor
+    next_value: torch.Tensor
+    reward: torch.Tensor
+    done: torch.Tensor
+    terminated: torch.Tensor
+    gamma_t: Optional[torch.Tensor]
+    gamma: float
+    rho_thresh: float
+    c_thresh: float
+
+
+def _thresh(x) -> float:
+    # functional.py:1311-1314: python thresholds become 0-dim default-dtype tensors
+    if isinstance(x, torch.Tensor):
+        if x.numel() != 1:
+            raise NotImplementedError("vtrace_advantage_estimate: per-element clipping thresholds are not supported")
+        return float(x)
+    return _round_to(float(x), torch.get_default_dtype())
+
+
+def _prepare_vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward, done, terminated, rho_thresh,
+                    c_thresh, time_dim) -> _VtraceCall:
+    if not (next_state_value.shape == state_value.shape == reward.shape == done.shape):
+        raise RuntimeError(SHAPE_ERR)
+    if terminated is None:
+        terminated = done  # functional.py:1320
+    shape = tuple(next_state_value.shape)
+    O, T, I, _ = _canonical_dims(shape, time_dim)
+    vdt = _check_value_dtype(reward, state_value, next_state_value, log_pi, log_mu)
+    dev = next_state_value.device
+    gamma_t = None
+    g_val = 0.0
+    if _is_full(gamma):
+        cdt = _mask_coef_dtype(gamma)
+        gamma_t = _expand_coef(gamma.detach(), shape, time_dim).to(device=dev, dtype=cdt).contiguous()
+    else:
+        g_val, cdt = _scalar_mask_coef(gamma)
+    if cdt not in _DT:
+        raise NotImplementedError(f"gamma dtype {cdt} is not supported (float32 / float64 only)")
+
+    def bc(t):
+        return t if tuple(t.shape) == shape else _expand_coef(t, shape, time_dim)
+
+    return _VtraceCall(shape=shape, O=O, T=T, I=I, vdt=vdt, cdt=cdt, log_pi=_val(bc(log_pi), vdt, dev),
+                       log_mu=_val(bc(log_mu), vdt, dev), value=_val(state_value, vdt, dev),
+                       next_value=_val(next_state_value, vdt, dev), reward=_val(reward, vdt, dev),
+                       done=_mask(done, shape, dev), terminated=_mask(terminated, shape, dev), gamma_t=gamma_t,
+                       gamma=g_val, rho_thresh=_thresh(rho_thresh), c_thresh=_thresh(c_thresh))
+
+
+def _launch_vtrace(c: _VtraceCall, algo: int = ALGO_AUTO):
+    lib = _extension.get_lib()
+    _require_hip(c.next_value)
+    dev = c.next_value.device
+    odt = torch.promote_types(c.vdt, c.cdt)
+    adv = torch.empty(c.shape, dtype=odt, device=dev)
+    vs = torch.empty(c.shape, dtype=odt, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.trl_vtrace_fwd(
+            _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.log_pi), _ptr(c.log_mu), _ptr(c.value), _ptr(c.next_value),
+            _ptr(c.reward), _ptr(c.done), _ptr(c.terminated), _ptr(c.gamma_t), c.gamma, c.rho_thresh, c.c_thresh,
+            c.O, c.T, c.I, _ptr(adv), _ptr(vs), algo)
+    _extension.check(rc, lib)
+    return adv, vs
+
+
+def vtrace_advantage_estimate(
+    gamma: float,
+    log_pi: torch.Tensor,
+    log_mu: torch.Tensor,
+    state_value: torch.Tensor,
+    next_state_value: torch.Tensor,
+    reward: torch.Tensor,
+    done: torch.Tensor,
+    terminated: torch.Tensor | None = None,
+    rho_thresh: Union[float, torch.Tensor] = 1.0,
+    c_thresh: Union[float, torch.Tensor] = 1.0,
+    # not a kwarg because used directly
+    time_dim: int = -2,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """V-Trace off-policy actor critic targets (reference: functional.py:1270-1350).
+
+    Returns ``(advantages, vs)``.  ``terminated=None`` makes ``not_terminated = not_done``.
+    """
+    if _needs_grad(log_pi, log_mu, state_value, next_state_value, reward, gamma):
+        raise NotImplementedError(_GRAD_MSG.format("vtrace_advantage_estimate"))
+    call = _prepare_vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward, done, terminated,
+                           rho_thresh, c_thresh, time_dim)
+    return _launch_vtrace(call)
+
+
+# ---------------------------------------------------------------------------------------------
+# TD(0), TD(1), reward-to-go -- "next" rows of SURVEY.md 8(f): thin compositions over the
+# kernels above (TD(1) is TD(lambda) with lmbda = 1, exactly as functional.py:691-700 does).
+# ---------------------------------------------------------------------------------------------
+def td0_return_estimate(
+    gamma: float,
+    next_state_value: torch.Tensor,
+    reward: torch.Tensor,
+    terminated: torch.Tensor | None = None,
+    *,
+    done: torch.Tensor | None = None,
+) -> torch.Tensor:
+    """TD(0) discounted return estimate (reference: functional.py:418-456); elementwise."""
+    if done is not None and terminated is None:
+        terminated = done.clone()
+        warnings.warn("done for td0_return_estimate is deprecated. Pass ``terminated`` instead.")
+    if not (next_state_value.shape == reward.shape == terminated.shape):
+        raise RuntimeError(SHAPE_ERR)
+    not_terminated = (~terminated).int()
+    return reward + gamma * not_terminated * next_state_value
+
+
+def td0_advantage_estimate(
+    gamma: float,
+    state_value: torch.Tensor,
+    next_state_value: torch.Tensor,
+    reward: torch.Tensor,
+    done: torch.Tensor,
+    terminated: torch.Tensor | None = None,
+) -> torch.Tensor:
+    """TD(0) advantage estimate (reference: functional.py:378-415); elementwise."""
+    if terminated is None:
+        terminated = done.clone()
+    _check5(state_value, next_state_value, reward, done, terminated)
+    return td0_return_estimate(gamma, next_state_value, reward, terminated) - state_value
+
+
+def vec_td1_return_estimate(
+    gamma,
+    next_state_value,
+    reward,
+    done: torch.Tensor,
+    terminated: torch.Tensor | None = None,
+    rolling_gamma: Optional[bool] = None,
+    time_dim: int = -2,
+):
+    """Vectorized TD(1) return estimate (reference: functional.py:641-700)."""
+    return vec_td_lambda_return_estimate(gamma=gamma, next_state_value=next_state_value, reward=reward, done=done,
+                                         terminated=terminated, rolling_gamma=rolling_gamma, lmbda=1, time_dim=time_dim)
+
+
+def td1_return_estimate(
+    gamma: float,
+    next_state_value: torch.Tensor,
+    reward: torch.Tensor,
+    done: torch.Tensor,
+    terminated: torch.Tensor | None = None,
+    rolling_gamma: bool = None,
+    *,
+    time_dim: int = -2,
+) -> torch.Tensor:
+    """TD(1) return estimate (reference: functional.py:464-562).
+
+    The reference loop ``g = r + gamma*nt*((1-dnt)*g + dnt*v')`` with ``dnt = done & ~terminated``
+    equals the TD(lambda) recurrence at ``lmbda = 1`` (``g <- g*(1-done) + v'*nt*done`` then
+    ``g = r + gamma*g``) for 0/1 masks; it runs on the TD(lambda) kernels."""
+    if terminated is None:
+        terminated = done
+    if not (next_state_value.shape == reward.shape == done.shape == terminated.shape):
+        raise RuntimeError(SHAPE_ERR)
+    single_gamma = not (isinstance(gamma, torch.Tensor) and gamma.shape == done.shape)
+    if rolling_gamma is not None and not rolling_gamma and single_gamma:
+        raise RuntimeError("rolling_gamma=False is expected only with time-sensitive gamma values")
+    return td_lambda_return_estimate(gamma, 1.0, next_state_value, reward, done, terminated,
+                                     rolling_gamma if not single_gamma else None, time_dim=time_dim)
+
+
+def td1_advantage_estimate(
+    gamma: float,
+    state_value: torch.Tensor,
+    next_state_value: torch.Tensor,
+    reward: torch.Tensor,
+    done: torch.Tensor,
+    terminated: torch.Tensor | None = None,
+    rolling_gamma: bool = None,
+    time_dim: int = -2,
+) -> torch.Tensor:
+    """TD(1) advantage estimate (reference: functional.py:565-638)."""
+    if terminated is None:
+        terminated = done
+    _check5(state_value, next_state_value, reward, done, terminated)
+    return td1_return_estimate(gamma, next_state_value, reward, done, terminated=terminated,
+                               rolling_gamma=rolling_gamma, time_dim=time_dim) - state_value
+
+
+def vec_td1_advantage_estimate(
+    gamma,
+    state_value,
+    next_state_value,
+    reward,
+    done: torch.Tensor,
+    terminated: torch.Tensor | None = None,
+    rolling_gamma: bool = None,
+    time_dim: int = -2,
+):
+    """Vectorized TD(1) advantage estimate (reference: functional.py:703-775)."""
+    if terminated is None:
+        terminated = done
+    _check5(state_value, next_state_value, reward, done, terminated)
+    return vec_td1_return_estimate(gamma, next_state_value, reward, done=done, terminated=terminated,
+                                   rolling_gamma=rolling_gamma, time_dim=time_dim) - state_value
+
+
+def reward2go(reward, done, gamma, *, time_dim: int = -2):
+    """Discounted cumulative sum of rewards per trajectory (reference: functional.py:1358-1432).
+
+    ``R_t = r_t + gamma * (1-done_t) * R_{t+1}`` restarting after every ``done`` and at the end
+    of every row: GAE with ``v = v' = 0`` and ``lmbda*gamma -> gamma``.  Like the reference, a
+    tensor with more than two dims is flattened so that trailing dims are independent rows."""
+    if reward.shape != done.shape:
+        raise ValueError(f"reward and done must share the same shape, got {reward.shape} and {done.shape}")
+    zeros = torch.zeros_like(reward)
+    one = torch.ones((), dtype=reward.dtype if reward.dtype.is_floating_point else torch.get_default_dtype())
+    g = one * gamma if not isinstance(gamma, torch.Tensor) else gamma
+    call = _prepare_gae(1.0, g, zeros, zeros, reward, done, torch.ones_like(done, dtype=torch.bool), time_dim)
+    adv, _, _ = _launch_gae(call)
+    return adv
