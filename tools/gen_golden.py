@@ -336,8 +336,8 @@ def gen_checksums(F):
         gamma = (0.9 + 0.1 * torch.rand(shape, generator=g, dtype=torch.float32)).to(DT[dt])
         term = torch.rand(shape, generator=g) < 0.001
         done = term | (torch.rand(shape, generator=g) < 0.001)
-        log_pi = torch.rand(shape, generator=g).clamp_min(1e-6).log().to(DT[dt])
-        log_mu = torch.rand(shape, generator=g).clamp_min(1e-6).log().to(DT[dt])
+        log_pi = torch.rand(shape, generator=g).clamp_min(1e-6).double().log().to(DT[dt])  # f64 log: f32 log differs by an ulp across hosts
+        log_mu = torch.rand(shape, generator=g).clamp_min(1e-6).double().log().to(DT[dt])
         ret = F.td_lambda_return_estimate(gamma, 0.95, nv, r, done, term)
         out[f"C5_tdlambda_{dt}"] = dict(seed=0, shape=list(shape), lmbda=0.95, returns=summarize(ret))
         adv, vs = F.vtrace_advantage_estimate(gamma, log_pi, log_mu, v, nv, r, done, term)
