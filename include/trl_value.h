@@ -54,8 +54,10 @@ enum {
 enum {
     TRL_ALGO_AUTO = 0,
     TRL_ALGO_SEQ = 1, /* one lane per (o,i) row, sequential over t: bit-identical to the reference loop */
-    TRL_ALGO_SCAN = 2 /* wavefront scan of affine maps over time (I == 1): tolerance-level parity,
-                         bit-exact at done boundaries */
+    TRL_ALGO_SCAN = 2, /* wavefront scan of affine maps over time (I == 1): tolerance-level parity,
+                          bit-exact at done boundaries */
+    TRL_ALGO_FUSED = 3 /* trl_gae_normalize_fwd only: single persistent launch, advantages kept in
+                          registers across an in-launch all-gather of the fp64 moments */
 };
 
 int trl_abi_version(void);
@@ -63,7 +65,10 @@ const char *trl_last_error(void);
 /* Name of the kernel family the last successful call on this thread dispatched to. */
 const char *trl_last_kernel(void);
 
-/* Bytes of device workspace the calls below need for a problem of this size (per call). */
+/* Bytes of device workspace the calls below need for a problem of this size.  The workspace must be
+ * 256-byte aligned and ZERO-FILLED ONCE before its first use (it carries the epoch of the fused
+ * kernel's in-launch exchange); afterwards only this library writes it.  Calls that share a
+ * workspace must not overlap in time (one workspace per stream). */
 size_t trl_workspace_bytes(int64_t O, int64_t T, int64_t I);
 
 /*
@@ -89,6 +94,26 @@ int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype,
                 int64_t O, int64_t T, int64_t I,
                 void *advantage, void *value_target,
                 double *stats, void *workspace, size_t workspace_bytes, int algo);
+
+/*
+ * GAE followed by advantage normalisation over ALL elements -- the north-star step.
+ * Replaces: GAE.forward with average_gae=True (torchrl/objectives/value/advantages.py:1436-1463):
+ *   adv, value_target = gae(...);  adv = (adv - adv.mean()) / adv.std().clamp_min(eps)
+ * Arguments as trl_gae_fwd; `advantage` receives the NORMALISED advantage.  `stats` (optional,
+ * device double[3]) receives {N, sum(A), sum(A^2)} of the un-normalised advantage.
+ * AUTO uses the single-launch FUSED kernel when the shape is eligible (I == 1, short rows, the
+ * advantages fit in registers: up to 4 * #CUs * 1024 * V transitions), otherwise
+ * trl_gae_fwd + trl_normalize.  Single-GPU only: a batch sharded over GPUs uses trl_gae_fwd
+ * (stats) -> all-reduce -> trl_normalize.
+ */
+int trl_gae_normalize_fwd(void *stream, int val_dtype, int coef_dtype,
+                          const void *reward, const void *state_value, const void *next_state_value,
+                          const uint8_t *done, const uint8_t *terminated,
+                          const void *gamma_t, const void *lg_t,
+                          double gamma, double lmbda, double lg,
+                          int64_t O, int64_t T, int64_t I,
+                          void *advantage, void *value_target, double eps,
+                          double *stats, void *workspace, size_t workspace_bytes, int algo);
 
 /*
  * TD(lambda) return.

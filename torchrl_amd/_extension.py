@@ -45,6 +45,8 @@ _PROTOTYPES = {
     "trl_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "trl_gae_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl,
                            _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _int]),
+    "trl_gae_normalize_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl,
+                                     _i64, _i64, _i64, _vp, _vp, _dbl, _vp, _vp, _sz, _int]),
     "trl_td_lambda_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int,
                                  _i64, _i64, _i64, _vp, _int]),
     "trl_vtrace_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl,

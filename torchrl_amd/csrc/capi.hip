@@ -36,6 +36,11 @@ int check_dims(const char *fn, i64 O, i64 T, i64 I) {
     return TRL_OK;
 }
 
+// workspace layout: [0, kFusedWsBytes) fused-kernel header (epoch, error, moment slots);
+// [kFusedWsBytes, +64) scratch {N, sum, sumsq}; then the per-block partials.
+constexpr size_t kWsStatsOffset = kFusedWsBytes;
+constexpr size_t kWsPartialsOffset = kFusedWsBytes + 64;
+
 i64 max_partials(i64 O, i64 T, i64 I) {
     i64 a = seq_max_partials(O, T, I), b = scan_max_partials(O, T, I), c = moments_max_partials(O * T * I);
     i64 m = a > b ? a : b;
@@ -52,7 +57,7 @@ const char *trl_last_kernel(void) { return g_kernel; }
 
 size_t trl_workspace_bytes(int64_t O, int64_t T, int64_t I) {
     if (O <= 0 || T <= 0 || I <= 0) return 0;
-    return (size_t)max_partials(O, T, I) * 2 * sizeof(double) + 256;
+    return kWsPartialsOffset + (size_t)max_partials(O, T, I) * 2 * sizeof(double) + 256;
 }
 
 int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
@@ -72,7 +77,7 @@ int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward,
         if (((uintptr_t)workspace & 7) != 0) return fail(TRL_ERR_WORKSPACE, "trl_gae_fwd: workspace must be 8-byte aligned");
     }
     GaeArgs a{reward, state_value, next_state_value, done, terminated, gamma_t, lg_t, gamma, lmbda, lg,
-              O, T, I, advantage, value_target, stats ? (double *)workspace : nullptr};
+              O, T, I, advantage, value_target, stats ? (double *)((char *)workspace + kWsPartialsOffset) : nullptr};
     hipStream_t s = (hipStream_t)stream;
     if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ)
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: unknown algo %d", algo);
@@ -84,7 +89,8 @@ int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward,
     if (res.status != 0) return fail(res.status, "trl_gae_fwd: launch rejected (grid too large?)");
     if (int rc = check_launch("trl_gae_fwd")) return rc;
     if (stats) {
-        launch_reduce_partials(s, (const double *)workspace, res.npartials, (double)O * (double)T * (double)I, stats);
+        launch_reduce_partials(s, (const double *)((char *)workspace + kWsPartialsOffset), res.npartials,
+                               (double)O * (double)T * (double)I, stats);
         if (int rc = check_launch("trl_gae_fwd(stats)")) return rc;
     }
     g_kernel = res.kernel;
@@ -141,6 +147,44 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_
     return TRL_OK;
 }
 
+int trl_gae_normalize_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
+                          const void *next_state_value, const uint8_t *done, const uint8_t *terminated,
+                          const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
+                          int64_t O, int64_t T, int64_t I, void *advantage, void *value_target, double eps,
+                          double *stats, void *workspace, size_t workspace_bytes, int algo) {
+    if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_normalize_fwd: bad dtype");
+    if (int rc = check_dims("trl_gae_normalize_fwd", O, T, I)) return rc;
+    if (!reward || !state_value || !next_state_value || !done || !terminated || !advantage || !value_target)
+        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_normalize_fwd: null tensor pointer");
+    if (lg_t && !gamma_t) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_normalize_fwd: lg_t given without gamma_t");
+    if (!workspace || workspace_bytes < trl_workspace_bytes(O, T, I) || ((uintptr_t)workspace & 255) != 0)
+        return fail(TRL_ERR_WORKSPACE, "trl_gae_normalize_fwd: workspace is %zu bytes, need %zu (256-byte aligned, zero-filled once)",
+                    workspace_bytes, trl_workspace_bytes(O, T, I));
+    if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ && algo != TRL_ALGO_FUSED)
+        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_normalize_fwd: unknown algo %d", algo);
+    hipStream_t s = (hipStream_t)stream;
+    if (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_FUSED) {
+        GaeArgs a{reward, state_value, next_state_value, done, terminated, gamma_t, lg_t, gamma, lmbda, lg,
+                  O, T, I, advantage, value_target, nullptr};
+        LaunchResult res = launch_gae_fused(s, val_dtype, coef_dtype, a, eps, workspace, stats);
+        if (res.status == 0) {
+            if (int rc = check_launch("trl_gae_normalize_fwd(fused)")) return rc;
+            g_kernel = res.kernel;
+            return TRL_OK;
+        }
+        if (res.status != TRL_ERR_UNSUPPORTED) return fail(res.status, "trl_gae_normalize_fwd: fused launch rejected");
+        if (algo == TRL_ALGO_FUSED)
+            return fail(TRL_ERR_UNSUPPORTED, "trl_gae_normalize_fwd: FUSED family needs I == 1, T <= 256*V and at most "
+                                             "4 chunks per team (advantages are kept in registers)");
+    }
+    double *st = stats ? stats : (double *)((char *)workspace + kWsStatsOffset);
+    if (int rc = trl_gae_fwd(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated, gamma_t,
+                             lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, st, workspace, workspace_bytes,
+                             algo == TRL_ALGO_FUSED ? TRL_ALGO_AUTO : algo))
+        return rc;
+    return trl_normalize(stream, val_dtype, advantage, O * T * I, st, eps, advantage);
+}
+
 int trl_normalize(void *stream, int dtype, const void *x, int64_t n, const double *stats, double eps, void *out) {
     if (!dtype_ok(dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_normalize: bad dtype");
     if (n <= 0 || !x || !out || !stats) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_normalize: null pointer or n <= 0");
@@ -157,9 +201,10 @@ int trl_moments(void *stream, int dtype, const void *x, int64_t n, double *stats
         return fail(TRL_ERR_WORKSPACE, "trl_moments: workspace is %zu bytes, need %zu (8-byte aligned)", workspace_bytes,
                     trl_workspace_bytes(n, 1, 1));
     i64 np = 0;
-    launch_moments((hipStream_t)stream, dtype, x, n, (double *)workspace, &np);
+    double *partials = (double *)((char *)workspace + kWsPartialsOffset);
+    launch_moments((hipStream_t)stream, dtype, x, n, partials, &np);
     if (int rc = check_launch("trl_moments")) return rc;
-    launch_reduce_partials((hipStream_t)stream, (const double *)workspace, np, (double)n, stats);
+    launch_reduce_partials((hipStream_t)stream, partials, np, (double)n, stats);
     if (int rc = check_launch("trl_moments(reduce)")) return rc;
     g_kernel = "moments";
     return TRL_OK;

@@ -15,11 +15,40 @@ struct Promote { using type = double; };
 template <>
 struct Promote<float, float> { using type = float; };
 
+// ---- DPP lane movement (no LDS crossbar, a few cycles instead of a ds_bpermute round trip) ------
+// CTRL: quad_perm 0x00-0xff, row_shl:n 0x100+n (lane i reads lane i+n of its 16-lane row),
+// row_shr:n 0x110+n, wave_shl:1 0x130 (lane i reads lane i+1 across the wave), row_mirror 0x140,
+// row_half_mirror 0x141.  Lanes without a source read 0 (bound_ctrl).
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, dpp_mov<CTRL>(__builtin_bit_cast(int, x)));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = dpp_mov<CTRL>((int)(b & 0xffffffffLL)), hi = dpp_mov<CTRL>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double readlane_d(double x, int lane) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+
 // ---- wave / block reductions (fixed order => deterministic) -------------------------------
+// Sum over the 64 lanes; the result is wave-uniform.  Butterfly inside each 16-lane row with
+// DPP (xor 1, xor 2, half-mirror, mirror), then the four row totals are added in lane order.
 __device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, kWave);
-    return x;  // valid in lane 0
+    x += dpp_mov<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += dpp_mov<0x141>(x);  // row_half_mirror
+    x += dpp_mov<0x140>(x);  // row_mirror
+    return ((readlane_d(x, 0) + readlane_d(x, 16)) + readlane_d(x, 32)) + readlane_d(x, 48);
 }
 
 // Reduce (s, ss) over a block of NT threads; result valid in thread 0.
@@ -39,6 +68,19 @@ __device__ __forceinline__ void block_sum2(double &s, double &ss, double *smem /
             for (int k = 1; k < NW; ++k) { s += smem[2 * k]; ss += smem[2 * k + 1]; }
         }
     }
+}
+
+// mean / clamped std in the storage dtype from {N, sum, sumsq}: what
+// `x.mean()` / `x.std().clamp_min(eps)` give (unbiased std; advantages.py:1459-1463).
+template <typename TS>
+__device__ __forceinline__ void mean_std(double n, double s, double ss, double eps, TS &mean_s, TS &std_s) {
+    const double mean = s / n;
+    double var = (ss - n * mean * mean) / (n - 1.0);  // unbiased, as torch.std
+    if (var < 0.0) var = 0.0;                         // rounding only; NaN (n == 1) stays NaN
+    mean_s = (TS)mean;
+    std_s = (TS)sqrt(var);
+    const TS eps_s = (TS)eps;
+    if (std_s < eps_s) std_s = eps_s;                 // clamp_min keeps NaN
 }
 
 // Parameter blocks (POD, passed by value to the kernels).
@@ -88,3 +130,7 @@ int launch_reduce_partials(hipStream_t s, const double *partials, i64 npartials,
 int launch_moments(hipStream_t s, int dt, const void *x, i64 n, double *partials, i64 *npartials);
 i64 moments_max_partials(i64 n);
 int launch_normalize(hipStream_t s, int dt, const void *x, i64 n, const double *stats, double eps, void *out);
+
+// Fused single-launch GAE + normalisation (fused_kernels.hip).  status 2 = shape not eligible.
+constexpr size_t kFusedWsBytes = 16384;  // header + per-block moment slots, at the start of the workspace
+LaunchResult launch_gae_fused(hipStream_t s, int vdt, int cdt, const GaeArgs &a, double eps, void *ws, double *stats_out);

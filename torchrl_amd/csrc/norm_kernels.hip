@@ -50,25 +50,12 @@ __global__ __launch_bounds__(kRedThreads) void moments_kernel(const TS *__restri
 template <typename TS>
 struct Vec4 { TS x, y, z, w; };
 
-// mean / clamped std in the storage dtype, from {N, sum, sumsq}.
-template <typename TS>
-__device__ __forceinline__ void mean_std(const double *__restrict__ stats, double eps, TS &mean_s, TS &std_s) {
-    const double n = stats[0], s = stats[1], ss = stats[2];
-    const double mean = s / n;
-    double var = (ss - n * mean * mean) / (n - 1.0);  // unbiased, as torch.std
-    if (var < 0.0) var = 0.0;                         // rounding only; NaN (n == 1) stays NaN
-    mean_s = (TS)mean;
-    std_s = (TS)sqrt(var);
-    const TS eps_s = (TS)eps;
-    if (std_s < eps_s) std_s = eps_s;                 // clamp_min keeps NaN
-}
-
 template <typename TS>
 __global__ __launch_bounds__(kRedThreads) void normalize_kernel(const TS *__restrict__ x, i64 n,
                                                                 const double *__restrict__ stats, double eps,
                                                                 TS *__restrict__ out, int vec_ok) {
     TS mean_s, std_s;
-    mean_std<TS>(stats, eps, mean_s, std_s);
+    mean_std<TS>(stats[0], stats[1], stats[2], eps, mean_s, std_s);
     const i64 stride = (i64)gridDim.x * kRedThreads;
     const i64 tid = (i64)blockIdx.x * kRedThreads + threadIdx.x;
     if (vec_ok) {

@@ -1,0 +1,453 @@
+// Device-side core of the wavefront-scan kernels (shared by scan_kernels.hip and
+// fused_kernels.hip).  See scan_kernels.hip for the algorithm description.
+#pragma once
+#include "common.h"
+
+namespace scan {
+
+constexpr int kWaves = 4;                  // waves that share one chunk (one "team")
+constexpr int kTeam = kWaves * kWave;      // 256 lanes
+
+template <typename TC>
+struct Aff {
+    TC a, b;
+    int h;  // hard reset: the incoming value is ignored
+};
+
+// apply f2 first, then f1
+template <typename TC>
+__device__ __forceinline__ Aff<TC> compose(const Aff<TC> &f1, const Aff<TC> &f2) {
+    Aff<TC> r;
+    const TC t = f1.b + f1.a * f2.b;
+    r.a = f1.a * f2.a;
+    r.b = f1.h ? f1.b : t;
+    r.h = f1.h | f2.h;
+    return r;
+}
+template <typename TC>
+__device__ __forceinline__ TC apply(const Aff<TC> &f, TC x) {
+    const TC t = f.b + f.a * x;
+    return f.h ? f.b : t;
+}
+template <typename TC>
+__device__ __forceinline__ Aff<TC> shfl_down_aff(const Aff<TC> &f, int off) {
+    Aff<TC> r;
+    r.a = __shfl_down(f.a, off, kWave);
+    r.b = __shfl_down(f.b, off, kWave);
+    r.h = __shfl_down(f.h, off, kWave);
+    return r;
+}
+
+// ---- raw vector loads / stores (16 B per lane whenever the element type allows) -------------
+template <int BYTES>
+struct RawT;
+template <>
+struct RawT<2> { typedef unsigned short type; };
+template <>
+struct RawT<4> { typedef unsigned int type; };
+template <>
+struct RawT<8> { typedef uint2 type; };
+template <>
+struct RawT<16> { typedef uint4 type; };
+
+template <typename T, int V>
+__device__ __forceinline__ void vload(const T *__restrict__ p, T (&out)[V]) {
+    constexpr int B = V * (int)sizeof(T);
+    if constexpr (B <= 16) {
+        typename RawT<B>::type raw = *(const typename RawT<B>::type *)p;
+        __builtin_memcpy(out, &raw, B);
+    } else {
+        static_assert(B % 16 == 0, "vector width");
+#pragma unroll
+        for (int k = 0; k < B / 16; ++k) {
+            uint4 raw = ((const uint4 *)p)[k];
+            __builtin_memcpy((char *)out + 16 * k, &raw, 16);
+        }
+    }
+}
+template <typename T, int V>
+__device__ __forceinline__ void vstore(T *__restrict__ p, const T (&in)[V]) {
+    constexpr int B = V * (int)sizeof(T);
+    if constexpr (B <= 16) {
+        typename RawT<B>::type raw;
+        __builtin_memcpy(&raw, in, B);
+        *(typename RawT<B>::type *)p = raw;
+    } else {
+#pragma unroll
+        for (int k = 0; k < B / 16; ++k) {
+            uint4 raw;
+            __builtin_memcpy(&raw, (const char *)in + 16 * k, 16);
+            ((uint4 *)p)[k] = raw;
+        }
+    }
+}
+template <bool VEC, typename T, int V>
+__device__ __forceinline__ void load_n(const T *__restrict__ p, i64 flat, int nvalid, T (&out)[V]) {
+    if (VEC && nvalid == V) {
+        vload<T, V>(p + flat, out);
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) out[e] = e < nvalid ? p[flat + e] : (T)0;
+    }
+}
+template <bool VEC, typename T, int V>
+__device__ __forceinline__ void store_n(T *__restrict__ p, i64 flat, int nvalid, const T (&in)[V]) {
+    if (VEC && nvalid == V) {
+        vstore<T, V>(p + flat, in);
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+            if (e < nvalid) p[flat + e] = in[e];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ T clamp_max_nan(T x, T hi) { return (x != x) ? x : (x > hi ? hi : x); }
+__device__ __forceinline__ float exp_t(float x) { return expf(x); }
+__device__ __forceinline__ double exp_t(double x) { return exp(x); }
+
+// ---- per-estimator element logic -------------------------------------------------------------
+// Each Op holds one lane's V consecutive time steps.  Interface used by the scan driver:
+//   Raw / load<VEC>(args, flat, nvalid, raw)   issue the global loads (nothing else: lets the
+//                                              caller prefetch the next chunk)
+//   prepare(args, raw)              fuse the delta / coefficient math
+//   init(e)                         value the recurrence starts from at a row end
+//   step(e, x)                      x_t from x_{t+1}: the reference's exact per-step expression
+//   affine(e, a, b)                 the same step as an affine map (used for aggregates only)
+//   first_value()                   (V-trace) state_value of the lane's first step
+//   store<VEC>(...)                 epilogue + global stores (+ fp64 moments for GAE)
+
+template <typename TS_, typename TG_, int V_>
+struct GaeOp {
+    typedef TS_ TS;
+    typedef TG_ TG;
+    typedef typename Promote<TS, TG>::type TC;
+    typedef GaeArgs Args;
+    static constexpr int V = V_;
+    static constexpr bool kNeedsNext = false;
+    struct Raw {
+        TS r[V], v[V], nv[V];
+        u8 d[V], tm[V];
+        TG g[V], lg[V];
+    };
+    TS v[V];
+    TC delta[V], disc[V];
+
+    template <bool VEC>
+    static __device__ __forceinline__ void load(const Args &a, i64 flat, int nvalid, Raw &w) {
+        load_n<VEC>((const TS *)a.reward, flat, nvalid, w.r);
+        load_n<VEC>((const TS *)a.value, flat, nvalid, w.v);
+        load_n<VEC>((const TS *)a.next_value, flat, nvalid, w.nv);
+        load_n<VEC>(a.done, flat, nvalid, w.d);
+        load_n<VEC>(a.terminated, flat, nvalid, w.tm);
+        if (a.gamma_t) load_n<VEC>((const TG *)a.gamma_t, flat, nvalid, w.g);
+        if (a.lg_t) load_n<VEC>((const TG *)a.lg_t, flat, nvalid, w.lg);
+    }
+    __device__ __forceinline__ void prepare(const Args &a, const Raw &w) {
+        const TG gs = (TG)a.gamma, ls = (TG)a.lmbda, lgs = (TG)a.lg;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const TG ge = a.gamma_t ? w.g[e] : gs;
+            const TG ce = a.lg_t ? w.lg[e] : (a.gamma_t ? ls * ge : lgs);
+            const TG g_nt = ge * (TG)(w.tm[e] ? 0 : 1);  // multiply, not select: as the reference
+            v[e] = w.v[e];
+            disc[e] = (TC)(ce * (TG)(w.d[e] ? 0 : 1));
+            delta[e] = ((TC)w.r[e] + (TC)g_nt * (TC)w.nv[e]) - (TC)w.v[e];
+        }
+    }
+    __device__ __forceinline__ TC init(int) const { return (TC)0; }
+    __device__ __forceinline__ TC step(int e, TC x) const { return delta[e] + x * disc[e]; }
+    __device__ __forceinline__ void affine(int e, TC &a, TC &b) const { a = disc[e]; b = delta[e]; }
+    __device__ __forceinline__ TS first_value() const { return v[0]; }
+
+    // advantage / value_target of the lane's V steps + fp64 moments of the advantage
+    __device__ __forceinline__ void finish(int nvalid, const TC (&x)[V], TS (&adv)[V], TS (&vt)[V], double &s,
+                                           double &ss) const {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            adv[e] = (TS)x[e];
+            vt[e] = adv[e] + v[e];
+            if (e < nvalid) {
+                s += (double)adv[e];
+                ss += (double)adv[e] * (double)adv[e];
+            }
+        }
+    }
+    template <bool VEC>
+    __device__ __forceinline__ void store(const Args &a, i64 flat, int nvalid, const TC (&x)[V], const bool (&)[V],
+                                          TC, TS, double &s, double &ss) const {
+        TS adv[V], vt[V];
+        finish(nvalid, x, adv, vt, s, ss);
+        store_n<VEC>((TS *)a.advantage, flat, nvalid, adv);
+        store_n<VEC>((TS *)a.value_target, flat, nvalid, vt);
+    }
+};
+
+template <typename TS_, typename TG_, int V_>
+struct TdLambdaOp {
+    typedef TS_ TS;
+    typedef TG_ TG;
+    typedef typename Promote<TS, TG>::type TC;
+    typedef TdLambdaArgs Args;
+    static constexpr int V = V_;
+    static constexpr bool kNeedsNext = false;
+    struct Raw {
+        TS r[V], nv[V];
+        u8 d[V], tm[V];
+        TG g[V], l[V];
+    };
+    TS r[V], nvm[V], dn[V], omd[V];
+    TG gm[V], lm[V];
+
+    template <bool VEC>
+    static __device__ __forceinline__ void load(const Args &a, i64 flat, int nvalid, Raw &w) {
+        load_n<VEC>((const TS *)a.reward, flat, nvalid, w.r);
+        load_n<VEC>((const TS *)a.next_value, flat, nvalid, w.nv);
+        load_n<VEC>(a.done, flat, nvalid, w.d);
+        load_n<VEC>(a.terminated, flat, nvalid, w.tm);
+        if (a.gamma_t) load_n<VEC>((const TG *)a.gamma_t, flat, nvalid, w.g);
+        if (a.lmbda_t) load_n<VEC>((const TG *)a.lmbda_t, flat, nvalid, w.l);
+    }
+    __device__ __forceinline__ void prepare(const Args &a, const Raw &w) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            r[e] = w.r[e];
+            gm[e] = a.gamma_t ? w.g[e] : (TG)a.gamma;
+            lm[e] = a.lmbda_t ? w.l[e] : (TG)a.lmbda;
+            nvm[e] = w.nv[e] * (TS)(w.tm[e] ? 0 : 1);
+            dn[e] = (TS)(w.d[e] ? 1 : 0);
+            omd[e] = (TS)(w.d[e] ? 0 : 1);
+        }
+    }
+    // g starts from v'_{T-1} (functional.py:866)
+    __device__ __forceinline__ TC init(int e) const { return (TC)nvm[e]; }
+    __device__ __forceinline__ TC step(int e, TC x) const {
+        const TG oml = (TG)1 - lm[e];
+        const TC g1 = x * (TC)omd[e] + (TC)(nvm[e] * dn[e]);
+        return (TC)r[e] + (TC)gm[e] * ((TC)oml * (TC)nvm[e] + (TC)lm[e] * g1);
+    }
+    __device__ __forceinline__ void affine(int e, TC &a, TC &b) const {
+        const TG oml = (TG)1 - lm[e];
+        a = ((TC)gm[e] * (TC)lm[e]) * (TC)omd[e];
+        b = (TC)r[e] + (TC)gm[e] * ((TC)oml * (TC)nvm[e] + (TC)lm[e] * (TC)(nvm[e] * dn[e]));
+    }
+    __device__ __forceinline__ TS first_value() const { return (TS)0; }
+
+    template <bool VEC>
+    __device__ __forceinline__ void store(const Args &a, i64 flat, int nvalid, const TC (&x)[V], const bool (&)[V],
+                                          TC, TS, double &, double &) const {
+        TS out[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) out[e] = (TS)x[e];
+        store_n<VEC>((TS *)a.returns, flat, nvalid, out);
+    }
+};
+
+template <typename TS_, typename TG_, int V_>
+struct VtraceOp {
+    typedef TS_ TS;
+    typedef TG_ TG;
+    typedef typename Promote<TS, TG>::type TC;
+    typedef VtraceArgs Args;
+    static constexpr int V = V_;
+    static constexpr bool kNeedsNext = true;
+    struct Raw {
+        TS lp[V], lmu[V], v[V], nv[V], r[V];
+        u8 d[V], tm[V];
+        TG g[V];
+    };
+    TS v[V], nv[V], r[V], crho[V];
+    TG td[V];
+    TC coef[V], delta[V];
+
+    template <bool VEC>
+    static __device__ __forceinline__ void load(const Args &a, i64 flat, int nvalid, Raw &w) {
+        load_n<VEC>((const TS *)a.log_pi, flat, nvalid, w.lp);
+        load_n<VEC>((const TS *)a.log_mu, flat, nvalid, w.lmu);
+        load_n<VEC>((const TS *)a.value, flat, nvalid, w.v);
+        load_n<VEC>((const TS *)a.next_value, flat, nvalid, w.nv);
+        load_n<VEC>((const TS *)a.reward, flat, nvalid, w.r);
+        load_n<VEC>(a.done, flat, nvalid, w.d);
+        load_n<VEC>(a.terminated, flat, nvalid, w.tm);
+        if (a.gamma_t) load_n<VEC>((const TG *)a.gamma_t, flat, nvalid, w.g);
+    }
+    __device__ __forceinline__ void prepare(const Args &a, const Raw &w) {
+        const TS rho_hi = (TS)a.rho_thresh, c_hi = (TS)a.c_thresh;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            v[e] = w.v[e];
+            nv[e] = w.nv[e];
+            r[e] = w.r[e];
+            const TG ge = a.gamma_t ? w.g[e] : (TG)a.gamma;
+            const TG dd = ge * (TG)(w.d[e] ? 0 : 1);
+            td[e] = ge * (TG)(w.tm[e] ? 0 : 1);
+            const TS rho = exp_t(w.lp[e] - w.lmu[e]);
+            crho[e] = clamp_max_nan(rho, rho_hi);
+            const TS cc = clamp_max_nan(rho, c_hi);
+            delta[e] = (TC)crho[e] * (((TC)r[e] + (TC)td[e] * (TC)nv[e]) - (TC)v[e]);
+            coef[e] = (TC)dd * (TC)cc;
+        }
+    }
+    __device__ __forceinline__ TC init(int) const { return (TC)0; }
+    __device__ __forceinline__ TC step(int e, TC x) const { return delta[e] + coef[e] * x; }
+    __device__ __forceinline__ void affine(int e, TC &a, TC &b) const { a = coef[e]; b = delta[e]; }
+    __device__ __forceinline__ TS first_value() const { return v[0]; }
+
+    // x_next / v_next: x and state_value of the step that follows the lane's last step
+    // (only read when that step is not a row end).
+    template <bool VEC>
+    __device__ __forceinline__ void store(const Args &a, i64 flat, int nvalid, const TC (&x)[V], const bool (&row_end)[V],
+                                          TC x_next, TS v_next, double &, double &) const {
+        TC adv[V], vs[V];
+        TC vs_next = x_next + (TC)v_next;
+#pragma unroll
+        for (int e = V - 1; e >= 0; --e) {
+            vs[e] = x[e] + (TC)v[e];
+            const TC nxt = row_end[e] ? (TC)nv[e] : vs_next;  // shift ignores done, functional.py:1343-1345
+            adv[e] = (TC)crho[e] * (((TC)r[e] + (TC)td[e] * nxt) - (TC)v[e]);
+            if (e < nvalid) vs_next = vs[e];
+        }
+        store_n<VEC>((TC *)a.advantage, flat, nvalid, adv);
+        store_n<VEC>((TC *)a.vs, flat, nvalid, vs);
+    }
+};
+
+// ---- scan of one chunk by one team (kWaves waves) ---------------------------------------------
+template <class Op>
+struct TeamShared {
+    typename Op::TC a[2][kWaves], b[2][kWaves];
+    int h[2][kWaves];
+    typename Op::TS v0[2][kWaves];
+};
+
+// Geometry of one lane's slice of a chunk.
+struct LaneGeom {
+    i64 flat;      // flat index of the lane's first element
+    int nvalid;    // how many of its V elements exist
+    unsigned t0;   // time index of the lane's first element (mod T applied by the caller)
+};
+
+// Scan one chunk whose per-lane element data sits in `op` (already prepared).
+//   X (in/out): carry.  On entry x (and V-trace's state_value) of the element that follows the
+//   chunk; on exit those of the chunk's first element.  Ignored when WAVE_INDEP.
+//   scan_lanes: upper bound on the number of consecutive lanes one row spans (64 = no bound).
+//   emit(xs, row_end, x_in, v_next): consumes the per-step results.
+template <class Op, bool WAVE_INDEP, class Emit>
+__device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int buf, int nvalid, unsigned t0, unsigned T,
+                                           int scan_lanes, typename Op::TC &Xc, typename Op::TS &Xv, Emit &&emit) {
+    typedef typename Op::TC TC;
+    typedef typename Op::TS TS;
+    constexpr int V = Op::V;
+    const int lane = threadIdx.x & (kWave - 1), w = (threadIdx.x / kWave) & (kWaves - 1);
+
+    // time index of each element -> row-end flags
+    bool row_end[V];
+    {
+        unsigned t = t0;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            row_end[e] = (t == T - 1);
+            t = row_end[e] ? 0u : t + 1u;
+        }
+    }
+
+    // 1. lane aggregate
+    Aff<TC> agg{(TC)1, (TC)0, 0};
+#pragma unroll
+    for (int e = V - 1; e >= 0; --e) {
+        if (e < nvalid) {
+            Aff<TC> el;
+            if (row_end[e]) {
+                el.a = (TC)0;
+                el.b = op.step(e, op.init(e));
+                el.h = 1;
+            } else {
+                op.affine(e, el.a, el.b);
+                el.h = 0;
+            }
+            agg = (e == V - 1) ? el : compose(el, agg);
+        }
+    }
+
+    // 2. inclusive suffix scan over the wave (only as far as a row can reach): offsets 1..8 move
+    //    data with DPP row shifts inside each 16-lane row, then the rows are chained with two
+    //    cross-row steps (the totals of the following rows sit in lanes 16/32/48).
+    Aff<TC> S = agg;
+    const int lir = lane & 15;
+#define TRL_DPP_STEP(OFF)                                                          \
+    if (scan_lanes > OFF) {                                                        \
+        Aff<TC> p;                                                                 \
+        p.a = dpp_mov<0x100 + OFF>(S.a);                                           \
+        p.b = dpp_mov<0x100 + OFF>(S.b);                                           \
+        p.h = dpp_mov<0x100 + OFF>(S.h);                                           \
+        if (lir + OFF < 16) S = compose(S, p);                                     \
+    }
+    TRL_DPP_STEP(1)
+    TRL_DPP_STEP(2)
+    TRL_DPP_STEP(4)
+    TRL_DPP_STEP(8)
+#undef TRL_DPP_STEP
+    if (scan_lanes > 16) {
+        // rows 0 and 2 absorb the totals of rows 1 and 3, then rows 0 and 1 absorb rows 2..3
+        const int row = lane >> 4;
+        Aff<TC> p = Aff<TC>{__shfl(S.a, (row + 1) << 4, kWave), __shfl(S.b, (row + 1) << 4, kWave),
+                            __shfl(S.h, (row + 1) << 4, kWave)};
+        if ((row & 1) == 0) S = compose(S, p);
+        p = Aff<TC>{__shfl(S.a, 32, kWave), __shfl(S.b, 32, kWave), __shfl(S.h, 32, kWave)};
+        if (row < 2) S = compose(S, p);
+    }
+    // exclusive: everything after this lane, within the wave (whole-wave shift by one lane)
+    Aff<TC> E{dpp_mov<0x130>(S.a), dpp_mov<0x130>(S.b), dpp_mov<0x130>(S.h)};
+    if (lane == kWave - 1) E = Aff<TC>{(TC)1, (TC)0, 0};
+    TS v_next = Op::kNeedsNext ? dpp_mov<0x130>(op.first_value()) : (TS)0;
+
+    // 3. carry into this wave
+    TC Cw;
+    if constexpr (WAVE_INDEP) {
+        // every wave's range ends at a row end: the carry is never read
+        Cw = (TC)0;
+    } else {
+        if (lane == 0) {
+            sh.a[buf][w] = S.a;
+            sh.b[buf][w] = S.b;
+            sh.h[buf][w] = S.h;
+            if (Op::kNeedsNext) sh.v0[buf][w] = op.first_value();
+        }
+        __syncthreads();
+        TC x = Xc;
+        TS xv = Xv;
+        Cw = x;
+        TS Cv = xv;
+#pragma unroll
+        for (int k = kWaves - 1; k >= 0; --k) {
+            if (k == w) { Cw = x; Cv = xv; }
+            const Aff<TC> g{sh.a[buf][k], sh.b[buf][k], sh.h[buf][k]};
+            x = apply(g, x);
+            if (Op::kNeedsNext) xv = sh.v0[buf][k];
+        }
+        Xc = x;  // x of the chunk's first element
+        Xv = xv;
+        if (Op::kNeedsNext && lane == kWave - 1) v_next = Cv;
+    }
+
+    // 4. exact per-step replay from the lane's carry-in
+    TC xs[V];
+    const TC x_in = apply(E, Cw);
+    TC xp = x_in;
+#pragma unroll
+    for (int e = V - 1; e >= 0; --e) {
+        const TC xi = row_end[e] ? op.init(e) : xp;
+        xs[e] = op.step(e, xi);
+        if (e < nvalid) xp = xs[e];
+    }
+    emit(xs, row_end, x_in, v_next);
+}
+
+// lanes one row can span inside a wave (bounds the shuffle steps); 64 when unknown
+inline int scan_lanes_for(i64 T, int V, bool wave_indep) {
+    if (!wave_indep || T % V != 0) return kWave;
+    const i64 l = T / V;
+    return l < kWave ? (int)l : kWave;
+}
+
+}  // namespace scan

@@ -56,7 +56,7 @@ __all__ = [
 SHAPE_ERR = "All input tensors (value, reward and done states) must share a unique shape."
 _TIME_ERR = "The tensor shape and the time dimension are not compatible: got {} and time_dim={}."
 
-ALGO_AUTO, ALGO_SEQ, ALGO_SCAN = 0, 1, 2
+ALGO_AUTO, ALGO_SEQ, ALGO_SCAN, ALGO_FUSED = 0, 1, 2, 3
 _DT = {torch.float32: 0, torch.float64: 1}
 
 
@@ -302,23 +302,56 @@ def _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, term
     )
 
 
-def _launch_gae(c: _GaeCall, want_stats: bool = False, algo: int = ALGO_AUTO):
+_WORKSPACES = {}
+
+
+def _workspace(lib, dev, O, T, I):
+    """Per-(device, stream) workspace, zero-filled once (include/trl_value.h: it carries the
+    epoch of the fused kernel's in-launch exchange); grown on demand."""
+    need = lib.trl_workspace_bytes(O, T, I)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.zeros(max(need, 1 << 16), dtype=torch.uint8, device=dev)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+def _launch_gae(c: _GaeCall, want_stats: bool = False, algo: int = ALGO_AUTO, out=None):
     lib = _extension.get_lib()
     _require_hip(c.next_value)
     dev = c.next_value.device
-    adv = torch.empty(c.shape, dtype=c.vdt, device=dev)
-    vt = torch.empty(c.shape, dtype=c.vdt, device=dev)
+    adv, vt = out if out is not None else (torch.empty(c.shape, dtype=c.vdt, device=dev), torch.empty(c.shape, dtype=c.vdt, device=dev))
     stats = ws = None
     ws_bytes = 0
     if want_stats:
-        ws_bytes = lib.trl_workspace_bytes(c.O, c.T, c.I)
-        ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.float64, device=dev)
+        ws = _workspace(lib, dev, c.O, c.T, c.I)
+        ws_bytes = ws.numel()
         stats = torch.empty(3, dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
         rc = lib.trl_gae_fwd(
             _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.value), _ptr(c.next_value),
             _ptr(c.done), _ptr(c.terminated), _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg,
             c.O, c.T, c.I, _ptr(adv), _ptr(vt), _ptr(stats), _ptr(ws), ws_bytes, algo)
+    _extension.check(rc, lib)
+    if c.out_dtype != c.vdt:
+        adv, vt = adv.to(c.out_dtype), vt.to(c.out_dtype)
+    return adv, vt, stats
+
+
+def _launch_gae_normalize(c: _GaeCall, eps: float, algo: int = ALGO_AUTO, out=None, want_stats: bool = False):
+    """GAE + normalisation over all elements in one C-ABI call (single launch when eligible)."""
+    lib = _extension.get_lib()
+    _require_hip(c.next_value)
+    dev = c.next_value.device
+    adv, vt = out if out is not None else (torch.empty(c.shape, dtype=c.vdt, device=dev), torch.empty(c.shape, dtype=c.vdt, device=dev))
+    ws = _workspace(lib, dev, c.O, c.T, c.I)
+    stats = torch.empty(3, dtype=torch.float64, device=dev) if want_stats else None
+    with torch.cuda.device(dev):
+        rc = lib.trl_gae_normalize_fwd(
+            _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.value), _ptr(c.next_value),
+            _ptr(c.done), _ptr(c.terminated), _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg,
+            c.O, c.T, c.I, _ptr(adv), _ptr(vt), float(eps), _ptr(stats), _ptr(ws), ws.numel(), algo)
     _extension.check(rc, lib)
     if c.out_dtype != c.vdt:
         adv, vt = adv.to(c.out_dtype), vt.to(c.out_dtype)
@@ -379,6 +412,77 @@ def gae_with_stats(gamma, lmbda, state_value, next_state_value, reward, done, te
     return _launch_gae(call, want_stats=True, algo=algo)
 
 
+class PreparedStep:
+    """A fully-bound C-ABI call sequence (fixed buffers, fixed stream) that can be re-issued with
+    ``run()`` at the cost of the ctypes calls alone -- for callers that keep their rollout buffers
+    in place (training loops, hipGraph capture, benchmarks).  Holds references to every tensor."""
+
+    def __init__(self, calls, keep, outputs, stats=None):
+        self._calls, self._keep, self.outputs, self.stats = calls, keep, outputs, stats
+
+    def run(self):
+        for fn, args in self._calls:
+            rc = fn(*args)
+            if rc:
+                _extension.check(rc)
+        return self.outputs
+
+
+def prepare_gae_step(call: _GaeCall, eps: Optional[float] = None, *, normalize: bool = True, want_stats: bool = False,
+                     algo: int = ALGO_AUTO) -> PreparedStep:
+    """Bind GAE (+ normalisation) on ``call``'s tensors to the current stream.
+
+    ``normalize=True``: one ``trl_gae_normalize_fwd`` call (single launch when eligible).
+    ``normalize=False, want_stats=True``: ``trl_gae_fwd`` writing the fp64 moments to
+    ``PreparedStep.stats`` -- the caller all-reduces them and runs :func:`prepare_normalize`'s step."""
+    lib = _extension.get_lib()
+    _require_hip(c := call.next_value)
+    dev = c.device
+    adv = torch.empty(call.shape, dtype=call.vdt, device=dev)
+    vt = torch.empty(call.shape, dtype=call.vdt, device=dev)
+    ws = _workspace(lib, dev, call.O, call.T, call.I)
+    stats = torch.empty(3, dtype=torch.float64, device=dev) if (want_stats or not normalize) else None
+    head = (_stream(dev), _DT[call.vdt], _DT[call.cdt], _ptr(call.reward), _ptr(call.value), _ptr(call.next_value),
+            _ptr(call.done), _ptr(call.terminated), _ptr(call.gamma_t), _ptr(call.lg_t), call.gamma, call.lmbda, call.lg,
+            call.O, call.T, call.I, _ptr(adv), _ptr(vt))
+    if normalize:
+        calls = [(lib.trl_gae_normalize_fwd, head + (float(eps), _ptr(stats), _ptr(ws), ws.numel(), algo))]
+    else:
+        calls = [(lib.trl_gae_fwd, head + (_ptr(stats), _ptr(ws), ws.numel(), algo))]
+    return PreparedStep(calls, (call, ws), (adv, vt), stats)
+
+
+def prepare_normalize(x: torch.Tensor, stats: torch.Tensor, eps: float) -> PreparedStep:
+    """Bind the in-place scale pass ``x <- (x - mean) / max(std, eps)`` (moments read from ``stats``)."""
+    lib = _extension.get_lib()
+    _require_hip(x)
+    calls = [(lib.trl_normalize, (_stream(x.device), _DT[x.dtype], _ptr(x), x.numel(), _ptr(stats), float(eps), _ptr(x)))]
+    return PreparedStep(calls, (x, stats), (x,), stats)
+
+
+def gae_normalized(gamma, lmbda, state_value, next_state_value, reward, done, terminated=None, *, eps: float = 1e-4,
+                   time_dim=-2, group=None, distributed: bool = False, algo: int = ALGO_AUTO):
+    """GAE followed by ``(adv - adv.mean()) / adv.std().clamp_min(eps)`` over all elements: what
+    ``GAE(average_gae=True)`` computes (reference: advantages.py:1436-1463).  Returns
+    ``(normalised advantage, value_target)``.
+
+    Single GPU: one C-ABI call, one kernel launch when the shape is eligible (FUSED family).
+    ``distributed`` / ``group``: the batch is sharded over ranks along the env dimension; the
+    fp64 moments are all-reduced (one 24-byte RCCL all-reduce) between the GAE kernel and the
+    scale pass, so every rank normalises with the global statistics."""
+    if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
+        raise NotImplementedError(_GRAD_MSG.format("gae_normalized"))
+    call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
+    dist = torch.distributed
+    if (distributed or group is not None) and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        adv, vt, stats = _launch_gae(call, want_stats=True, algo=ALGO_AUTO if algo == ALGO_FUSED else algo)
+        dist.all_reduce(stats, group=group)
+        adv = normalize_(adv if adv.dtype == call.vdt else adv.to(call.vdt), stats, eps)
+        return adv, vt
+    adv, vt, _ = _launch_gae_normalize(call, eps, algo=algo)
+    return adv, vt
+
+
 # ---------------------------------------------------------------------------------------------
 # normalisation
 # ---------------------------------------------------------------------------------------------
@@ -390,11 +494,10 @@ def moments(x: torch.Tensor) -> torch.Tensor:
     if xc.dtype not in _DT:
         raise NotImplementedError(f"moments: dtype {xc.dtype} unsupported")
     n = xc.numel()
-    ws_bytes = lib.trl_workspace_bytes(n, 1, 1)
-    ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.float64, device=x.device)
+    ws = _workspace(lib, x.device, n, 1, 1)
     stats = torch.empty(3, dtype=torch.float64, device=x.device)
     with torch.cuda.device(x.device):
-        rc = lib.trl_moments(_stream(x.device), _DT[xc.dtype], _ptr(xc), n, _ptr(stats), _ptr(ws), ws_bytes)
+        rc = lib.trl_moments(_stream(x.device), _DT[xc.dtype], _ptr(xc), n, _ptr(stats), _ptr(ws), ws.numel())
     _extension.check(rc, lib)
     return stats
 
