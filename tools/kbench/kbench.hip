@@ -55,6 +55,29 @@ __global__ __launch_bounds__(256) void k_copy_pipe(const float4* r, const float4
     }
 }
 
+template <int MODE>  // 0 plain, 1 nontemporal stores, 2 nontemporal loads+stores
+__global__ __launch_bounds__(1024) void k_copy_pipe2(const float4* r, const float4* v, const float4* nv, const unsigned* d, const unsigned* t, float4* o1, float4* o2, i64 n4) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n4) return;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    auto ld4 = [](const float4* p) { if (MODE == 2) { f4 q = __builtin_nontemporal_load((const f4*)p); return make_float4(q.x, q.y, q.z, q.w); } return *p; };
+    auto ldu = [](const unsigned* p) { if (MODE == 2) return __builtin_nontemporal_load(p); return *p; };
+    auto st4 = [](float4* p, float4 x) { if (MODE >= 1) { f4 q = {x.x, x.y, x.z, x.w}; __builtin_nontemporal_store(q, (f4*)p); } else *p = x; };
+    float4 a = ld4(r + k), b = ld4(v + k), c = ld4(nv + k); unsigned x = ldu(d + k), y = ldu(t + k);
+    for (;;) {
+        const i64 kn = k + stride;
+        float4 an, bn, cn; unsigned xn = 0, yn = 0;
+        const bool more = kn < n4;
+        if (more) { an = ld4(r + kn); bn = ld4(v + kn); cn = ld4(nv + kn); xn = ldu(d + kn); yn = ldu(t + kn); }
+        float m = (x ^ y) ? 1.f : 0.5f;
+        st4(o1 + k, make_float4(a.x + c.x * m, a.y + c.y * m, a.z + c.z * m, a.w + c.w * m));
+        st4(o2 + k, make_float4(b.x + a.x, b.y + a.y, b.z + a.z, b.w + a.w));
+        if (!more) break;
+        a = an; b = bn; c = cn; x = xn; y = yn; k = kn;
+    }
+}
+
 int main(int argc, char** argv) {
     int iters = 300;
     float *r, *v, *nv, *o1, *o2, *sink; unsigned char *d, *t;
@@ -96,6 +119,16 @@ int main(int argc, char** argv) {
         char nm[64];
         snprintf(nm, 64, "copy_pipe 46.1MB grid=%d", g);
         run(nm, N * 22.0, [&] { hipLaunchKernelGGL(k_copy_pipe, dim3(g), dim3(256), 0, 0, (const float4*)r, (const float4*)v, (const float4*)nv, (const unsigned*)d, (const unsigned*)t, (float4*)o1, (float4*)o2, n4); });
+    }
+    for (int thr : {256, 1024}) for (int g : {256, 512, 1024}) {
+        if ((i64)g * thr > n4) continue;
+        char nm[64];
+        snprintf(nm, 64, "pipe2 plain thr=%d grid=%d", thr, g);
+        run(nm, N * 22.0, [&] { hipLaunchKernelGGL(k_copy_pipe2<0>, dim3(g), dim3(thr), 0, 0, (const float4*)r, (const float4*)v, (const float4*)nv, (const unsigned*)d, (const unsigned*)t, (float4*)o1, (float4*)o2, n4); });
+        snprintf(nm, 64, "pipe2 nt-store thr=%d grid=%d", thr, g);
+        run(nm, N * 22.0, [&] { hipLaunchKernelGGL(k_copy_pipe2<1>, dim3(g), dim3(thr), 0, 0, (const float4*)r, (const float4*)v, (const float4*)nv, (const unsigned*)d, (const unsigned*)t, (float4*)o1, (float4*)o2, n4); });
+        snprintf(nm, 64, "pipe2 nt-ld+st thr=%d grid=%d", thr, g);
+        run(nm, N * 22.0, [&] { hipLaunchKernelGGL(k_copy_pipe2<2>, dim3(g), dim3(thr), 0, 0, (const float4*)r, (const float4*)v, (const float4*)nv, (const unsigned*)d, (const unsigned*)t, (float4*)o1, (float4*)o2, n4); });
     }
     // empty-kernel launch cadence
     run("k_write n4=0 (launch cadence)", 1.0, [&] { hipLaunchKernelGGL(k_write, dim3(256), dim3(256), 0, 0, (float4*)o1, (float4*)o2, (i64)0); });

@@ -1,8 +1,10 @@
 // Ablation harness for the fused GAE+normalise kernel (development tool; not part of the product).
 #include "../../torchrl_amd/csrc/fused_kernels.hip"
+#include "../../torchrl_amd/csrc/norm_kernels.hip"
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#include <algorithm>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 constexpr i64 N = 65536LL * 32;
 typedef GaeOp<float, float, 4> Op;
@@ -24,15 +26,15 @@ void run(const char* name, GaeArgs a, FusedGeom geo, FusedWs* ws, int G, int ite
 int main() {
     float *r, *v, *nv, *o1, *o2; unsigned char *d, *t; FusedWs* ws;
     CK(hipMalloc(&r, N * 4)); CK(hipMalloc(&v, N * 4)); CK(hipMalloc(&nv, N * 4));
-    CK(hipMalloc(&o1, N * 4)); CK(hipMalloc(&o2, N * 4)); CK(hipMalloc(&d, N)); CK(hipMalloc(&t, N)); CK(hipMalloc(&ws, kFusedWsBytes));
-    CK(hipMemset(ws, 0, kFusedWsBytes));
+    CK(hipMalloc(&o1, N * 4)); CK(hipMalloc(&o2, N * 4)); CK(hipMalloc(&d, N)); CK(hipMalloc(&t, N)); CK(hipMalloc(&ws, 8 << 20));
+    CK(hipMemset(ws, 0, 8 << 20));
     std::vector<float> h(N); for (i64 i = 0; i < N; ++i) h[i] = (float)rand() / (float)RAND_MAX - 0.5f;
     CK(hipMemcpy(r, h.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(v, h.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(nv, h.data(), N * 4, hipMemcpyHostToDevice));
     std::vector<unsigned char> hm(N); for (i64 i = 0; i < N; ++i) hm[i] = (rand() % 100) == 0;
     CK(hipMemcpy(d, hm.data(), N, hipMemcpyHostToDevice)); CK(hipMemcpy(t, hm.data(), N, hipMemcpyHostToDevice));
     GaeArgs a{r, v, nv, d, t, nullptr, nullptr, 0.99f, 0.95f, 0.99f * 0.95f, 65536, 32, 1, o1, o2, nullptr};
     const int G = 256;
-    FusedGeom geo{65536, 32, 32, 8, 65536 / 32, (double)N, 1e-4};
+    FusedGeom geo{65536, 32, 32, 8, 65536 / 32, (double)N, 1e-4, 2};
     run<0, 2>("full", a, geo, ws, G, 300);
     run<1, 2>("no gather", a, geo, ws, G, 300);
     run<2, 2>("no gather, no block reduce", a, geo, ws, G, 300);
@@ -42,5 +44,44 @@ int main() {
     run<5, 2>("plain scan (adv+vt stored at once)", a, geo, ws, G, 300);
     run<6, 2>("plain scan + block partials", a, geo, ws, G, 300, part);
     run<0, 2>("full (again)", a, geo, ws, G, 300);
+    {   // two-launch alternative: persistent scan + partials, then scale pass reducing the partials itself
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int nbh : {256, 512, 1024, 2048}) {
+            auto f = [&] {
+                hipLaunchKernelGGL((gae_fused_kernel<Op, true, true, 2, 6>), dim3(G), dim3(kFusedThreads), 0, 0, a, geo, ws, part);
+                launch_normalize_from_partials(0, 0, o1, N, part, G, (double)N, 1e-4, o1, nullptr, nbh);
+            };
+            for (int i = 0; i < 20; ++i) f();
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < 300; ++i) f();
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("two launches: scan+partials, normalise(grid<=%d)   %8.2f us/step\n", nbh, ms * 1e3 / 300);
+        }
+    }
+    for (int stride : {16}) {
+      geo.slot_stride = stride;
+      printf("slot stride %d bytes\n", stride * 8);
+      run<0, 2>("  full", a, geo, ws, G, 300);
+      // per-block stamps (100 MHz wall clock): start, before publish, gather done, end
+        unsigned long long* dbg; CK(hipMalloc(&dbg, G * 32));
+        for (int rep = 0; rep < 3; ++rep) {
+            hipLaunchKernelGGL((gae_fused_kernel<Op, true, true, 2, 7>), dim3(G), dim3(kFusedThreads), 0, 0, a, geo, ws, (double*)dbg);
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> hdbg(G * 4);
+            CK(hipMemcpy(hdbg.data(), dbg, G * 32, hipMemcpyDeviceToHost));
+            unsigned long long t0min = ~0ull, t0max = 0, t1min = ~0ull, t1max = 0, t2min = ~0ull, t2max = 0, t3max = 0;
+            for (int b = 0; b < G; ++b) {
+                t0min = std::min(t0min, hdbg[4*b]); t0max = std::max(t0max, hdbg[4*b]);
+                t1min = std::min(t1min, hdbg[4*b+1]); t1max = std::max(t1max, hdbg[4*b+1]);
+                t2min = std::min(t2min, hdbg[4*b+2]); t2max = std::max(t2max, hdbg[4*b+2]);
+                t3max = std::max(t3max, hdbg[4*b+3]);
+            }
+            auto us = [&](unsigned long long t) { return (double)(t - t0min) * 0.01; };
+            printf("stamps[us from first block start]: start<=%.2f  publish %.2f..%.2f  gathered %.2f..%.2f  end<=%.2f\n",
+                   us(t0max), us(t1min), us(t1max), us(t2min), us(t2max), us(t3max));
+        }
+    }
     return 0;
 }

@@ -130,7 +130,9 @@ int launch_reduce_partials(hipStream_t s, const double *partials, i64 npartials,
 int launch_moments(hipStream_t s, int dt, const void *x, i64 n, double *partials, i64 *npartials);
 i64 moments_max_partials(i64 n);
 int launch_normalize(hipStream_t s, int dt, const void *x, i64 n, const double *stats, double eps, void *out);
+int launch_normalize_from_partials(hipStream_t s, int dt, const void *x, i64 n, const double *partials, i64 npartials,
+                                   double n_total, double eps, void *out, double *stats_out, int nblocks_hint);
 
 // Fused single-launch GAE + normalisation (fused_kernels.hip).  status 2 = shape not eligible.
-constexpr size_t kFusedWsBytes = 16384;  // header + per-block moment slots, at the start of the workspace
+constexpr size_t kFusedWsBytes = 256 + 512 * 128;  // header + one 128-byte slot line per block, at the start of the workspace
 LaunchResult launch_gae_fused(hipStream_t s, int vdt, int cdt, const GaeArgs &a, double eps, void *ws, double *stats_out);

@@ -38,9 +38,10 @@ struct FusedWs {
     unsigned epoch;
     unsigned error;
     unsigned pad[62];
-    unsigned long long slots[2 * kMaxBlocks];
+    unsigned long long slots[1];  // kMaxBlocks granule pairs, kSlotStride 8-byte units apart
 };
-static_assert(sizeof(FusedWs) <= kFusedWsBytes, "workspace header");
+constexpr int kSlotStride = 16;  // one 128-byte line per block: the polls of different blocks do not share a line
+static_assert(256 + (size_t)kMaxBlocks * kSlotStride * 8 <= kFusedWsBytes, "workspace header");
 
 struct FusedGeom {
     i64 O, T;
@@ -49,6 +50,7 @@ struct FusedGeom {
     i64 nchunks;
     double n_total;
     double eps;
+    int slot_stride;  // distance between two blocks' granule pairs, in 8-byte units
 };
 
 __device__ __forceinline__ unsigned long long tag_bits(double x, unsigned tag) {
@@ -77,6 +79,8 @@ __global__ __launch_bounds__(kFusedThreads) void gae_fused_kernel(typename Op::A
     const int lane_off = tid * V;
     const unsigned T = (unsigned)geo.T;
     const unsigned tag = (ws->epoch + 1u) & 0xffu;  // written by the previous launch: visible across the kernel boundary
+    unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
+    if constexpr (ABL == 7) stamp0 = wall_clock64();
 
     TS adv_keep[K][V];
     TS vt_last[V];
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(kFusedThreads) void gae_fused_kernel(typename Op::A
         return;
     }
     // ---- block moments -> publish -> gather everybody's --------------------------------------------
-    if constexpr (ABL == 0 || ABL == 1 || ABL == 4) {
+    if constexpr (ABL == 0 || ABL == 1 || ABL == 4 || ABL == 7) {
         s = wave_sum(s);
         ss = wave_sum(ss);
         if (lane == 0) {
@@ -175,38 +179,47 @@ __global__ __launch_bounds__(kFusedThreads) void gae_fused_kernel(typename Op::A
             bs += red[2 * k];
             bss += red[2 * k + 1];
         }
+        if constexpr (ABL == 7) stamp1 = wall_clock64();
         if (lane == 0) {
-            __hip_atomic_store(&ws->slots[2 * blockIdx.x], tag_bits(bs, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ws->slots[2 * blockIdx.x + 1], tag_bits(bss, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long *sl = ws->slots + (size_t)blockIdx.x * geo.slot_stride;
+            __hip_atomic_store(sl, tag_bits(bs, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sl + 1, tag_bits(bss, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const int nvals = 2 * (int)gridDim.x;  // even lanes collect sums, odd lanes sums of squares
-        constexpr int kPer = 2 * kMaxBlocks / kWave;
-        unsigned long long vals[kPer];
+        // lane l gathers blocks l, l+64, ...: only the granules still missing are re-polled
+        constexpr int kPer = kMaxBlocks / kWave;
+        unsigned long long vs[kPer], vq[kPer];
+        bool got[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) got[j] = lane + kWave * j >= (int)gridDim.x;
         const unsigned long long t_start = wall_clock64();
         bool ok;
         for (;;) {
             ok = true;
 #pragma unroll
             for (int j = 0; j < kPer; ++j) {
-                const int idx = lane + kWave * j;
-                vals[j] = 0;
-                if (idx < nvals) {
-                    vals[j] = __hip_atomic_load(&ws->slots[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = ok && ((unsigned)(vals[j] & 0xffull) == tag);
+                if (!got[j]) {
+                    const unsigned long long *sl = ws->slots + (size_t)(lane + kWave * j) * geo.slot_stride;
+                    vs[j] = __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vq[j] = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                if (!got[j]) got[j] = ((unsigned)(vs[j] & 0xffull) == tag) && ((unsigned)(vq[j] & 0xffull) == tag);
+                ok = ok && got[j];
             }
             if (__all(ok)) break;
             if (wall_clock64() - t_start > 100000000ull) break;  // 1 s at 100 MHz: give up loudly
             __builtin_amdgcn_s_sleep(1);
         }
         const bool all_ok = __all(ok);
-        double acc = 0.0;
+        if constexpr (ABL == 7) stamp2 = wall_clock64();
+        double acc = 0.0, acq = 0.0;
 #pragma unroll
         for (int j = 0; j < kPer; ++j)
-            if (lane + kWave * j < nvals) acc += untag(vals[j]);
-#pragma unroll
-        for (int off = 2; off < kWave; off <<= 1) acc += __shfl_xor(acc, off, kWave);
-        const double tot_ss = __shfl(acc, 1, kWave);
+            if (lane + kWave * j < (int)gridDim.x) { acc += untag(vs[j]); acq += untag(vq[j]); }
+        acc = wave_sum(acc);
+        const double tot_ss = wave_sum(acq);
         if (lane == 0) {
             const double nan = __longlong_as_double(0x7ff8000000000000LL);
             bc[0] = geo.n_total;
@@ -215,7 +228,7 @@ __global__ __launch_bounds__(kFusedThreads) void gae_fused_kernel(typename Op::A
             if (!all_ok) ws->error = 1u;
             if (blockIdx.x == 0) {
                 ws->epoch = ws->epoch + 1u;  // every block has read the old epoch: all of them have published
-                if (stats_out) {
+                if (stats_out && ABL != 7) {
                     stats_out[0] = geo.n_total;
                     stats_out[1] = bc[1];
                     stats_out[2] = bc[2];
@@ -234,6 +247,13 @@ __global__ __launch_bounds__(kFusedThreads) void gae_fused_kernel(typename Op::A
         store_n<VEC>((TS *)args.advantage, flat_k[k], nvalid_k[k], out);
     }
     if constexpr (kDeferVt) store_n<VEC>((TS *)args.value_target, flat_k[K - 1], nvalid_k[K - 1], vt_last);
+    if constexpr (ABL == 7) {
+        if (threadIdx.x == 0) {
+            unsigned long long *dbg = (unsigned long long *)stats_out + 4 * blockIdx.x;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dbg[0] = stamp0; dbg[1] = stamp1; dbg[2] = stamp2; dbg[3] = wall_clock64();
+        }
+    }
 }
 
 i64 gcd_i64(i64 a, i64 b) { while (b) { i64 t = a % b; a = b; b = t; } return a; }
@@ -273,7 +293,7 @@ LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *w
                     aligned16(a.value_target);
     const bool vec = al && (nchunks == 1 || (R * a.T) % V == 0);
     const bool wi = ((i64)kWave * V) % a.T == 0;
-    FusedGeom geo{a.O, a.T, (int)R, scan_lanes_for(a.T, V, wi), nchunks, (double)a.O * (double)a.T, eps};
+    FusedGeom geo{a.O, a.T, (int)R, scan_lanes_for(a.T, V, wi), nchunks, (double)a.O * (double)a.T, eps, kSlotStride};
     const dim3 grid((unsigned)G), block(kFusedThreads);
     FusedWs *w = (FusedWs *)ws;
 #define TRL_FUSED(VEC, WI, KK) hipLaunchKernelGGL((gae_fused_kernel<Op, VEC, WI, KK>), grid, block, 0, s, a, geo, w, stats_out)

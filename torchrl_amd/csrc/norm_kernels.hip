@@ -68,7 +68,52 @@ __global__ __launch_bounds__(kRedThreads) void normalize_kernel(const TS *__rest
             vec_t a = xv[k];
 #pragma unroll
             for (int e = 0; e < V; ++e) a[e] = (a[e] - mean_s) / std_s;
-            ov[k] = a;
+            __builtin_nontemporal_store(a, ov + k);
+        }
+        for (i64 k = nv * V + tid; k < n; k += stride) out[k] = (x[k] - mean_s) / std_s;
+    } else {
+        for (i64 k = tid; k < n; k += stride) out[k] = (x[k] - mean_s) / std_s;
+    }
+}
+
+// Scale pass that starts from the per-block partials of the producing kernel: every block sums
+// the (few hundred) partials itself in a fixed order -- no separate reduction launch -- then
+// streams its share of x.  Block 0 also writes {N, sum, sumsq} to stats_out (optional).
+template <typename TS>
+__global__ __launch_bounds__(kRedThreads) void normalize_from_partials_kernel(const TS *__restrict__ x, i64 n,
+                                                                              const double *__restrict__ partials,
+                                                                              int npartials, double n_total, double eps,
+                                                                              TS *__restrict__ out, double *stats_out,
+                                                                              int vec_ok) {
+    __shared__ double red[2 * kRedThreads / kWave];
+    __shared__ double bc[2];
+    double s = 0.0, ss = 0.0;
+    for (int k = threadIdx.x; k < npartials; k += kRedThreads) {
+        s += partials[2 * k];
+        ss += partials[2 * k + 1];
+    }
+    block_sum2<kRedThreads>(s, ss, red);
+    if (threadIdx.x == 0) {
+        bc[0] = s;
+        bc[1] = ss;
+        if (blockIdx.x == 0 && stats_out) { stats_out[0] = n_total; stats_out[1] = s; stats_out[2] = ss; }
+    }
+    __syncthreads();
+    TS mean_s, std_s;
+    mean_std<TS>(n_total, bc[0], bc[1], eps, mean_s, std_s);
+    const i64 stride = (i64)gridDim.x * kRedThreads;
+    const i64 tid = (i64)blockIdx.x * kRedThreads + threadIdx.x;
+    if (vec_ok) {
+        constexpr int V = 16 / sizeof(TS);
+        typedef TS vec_t __attribute__((ext_vector_type(V)));
+        const i64 nv = n / V;
+        const vec_t *__restrict__ xv = (const vec_t *)x;
+        vec_t *__restrict__ ov = (vec_t *)out;
+        for (i64 k = tid; k < nv; k += stride) {
+            vec_t a = xv[k];
+#pragma unroll
+            for (int e = 0; e < V; ++e) a[e] = (a[e] - mean_s) / std_s;
+            __builtin_nontemporal_store(a, ov + k);
         }
         for (i64 k = nv * V + tid; k < n; k += stride) out[k] = (x[k] - mean_s) / std_s;
     } else {
@@ -99,6 +144,20 @@ int launch_moments(hipStream_t s, int dt, const void *x, i64 n, double *partials
     else
         hipLaunchKernelGGL((moments_kernel<double>), dim3((unsigned)nb), dim3(kRedThreads), 0, s, (const double *)x, n, partials);
     *npartials = nb;
+    return 0;
+}
+
+int launch_normalize_from_partials(hipStream_t s, int dt, const void *x, i64 n, const double *partials, i64 npartials,
+                                   double n_total, double eps, void *out, double *stats_out, int nblocks_hint) {
+    const int vec_ok = (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
+    i64 nb = stream_blocks(n, dt == 0 ? 4 : 2);
+    if (nblocks_hint > 0 && nb > nblocks_hint) nb = nblocks_hint;
+    if (dt == 0)
+        hipLaunchKernelGGL((normalize_from_partials_kernel<float>), dim3((unsigned)nb), dim3(kRedThreads), 0, s, (const float *)x, n,
+                           partials, (int)npartials, n_total, eps, (float *)out, stats_out, vec_ok);
+    else
+        hipLaunchKernelGGL((normalize_from_partials_kernel<double>), dim3((unsigned)nb), dim3(kRedThreads), 0, s, (const double *)x, n,
+                           partials, (int)npartials, n_total, eps, (double *)out, stats_out, vec_ok);
     return 0;
 }
 
