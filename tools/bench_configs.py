@@ -1,0 +1,94 @@
+"""Time every BASELINE.json config on one GPU (development / documentation tool).
+
+Prints one line per (config, function): device time per call from HIP events over back-to-back
+calls with fixed buffers, transitions/s, algorithmic bytes and the fraction of the 8 TB/s HBM peak.
+    python tools/bench_configs.py [--iters 50]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torchrl_amd.objectives.value import functional as F  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, iters):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def inputs(shape, dtype, p, mask_shape=None):
+    g = torch.Generator().manual_seed(0)
+    mk = lambda: torch.randn(shape, generator=g, dtype=torch.float32).to(dtype).to(DEV)
+    r, v, nv = mk(), mk(), mk()
+    ms = mask_shape or shape
+    term = (torch.rand(ms, generator=g) < p).to(DEV)
+    done = term | (torch.rand(ms, generator=g) < p).to(DEV)
+    if mask_shape:
+        term, done = term.expand(shape), done.expand(shape)
+    gam = (0.9 + 0.1 * torch.rand(shape, generator=g)).to(dtype).to(DEV)
+    lp = torch.rand(shape, generator=g).clamp_min(1e-6).log().to(dtype).to(DEV)
+    lm = torch.rand(shape, generator=g).clamp_min(1e-6).log().to(dtype).to(DEV)
+    return r, v, nv, done, term, gam, lp, lm
+
+
+def report(name, us, n, bpt):
+    print(f"{name:58s} {us:9.2f} us  {n / us * 1e6:10.3e} trans/s  {n * bpt / 1e6:8.1f} MB  {n * bpt / us * 1e-3:8.1f} GB/s  {n * bpt / us * 1e-3 / 8000:6.1%}  [{F.last_kernel()}]")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    a = ap.parse_args()
+    it = a.iters
+    f32, f64 = torch.float32, torch.float64
+    # C1 / C2: latency-bound
+    for name, shape in (("C1 [1x2048]", (1, 2048, 1)), ("C2 [8x128]", (8, 128, 1))):
+        r, v, nv, d, t, gam, lp, lm = inputs(shape, f32, 0.005)
+        n = r.numel()
+        call = F._prepare_gae(0.99, 0.95, v, nv, r, d, t, -2)
+        st = F.prepare_gae_step(call, normalize=False, want_stats=False)
+        report(f"{name} GAE f32", timeit(st.run, it), n, 22)
+        report(f"{name} GAE f32 (python entry point)", timeit(lambda: F.generalized_advantage_estimate(0.99, 0.95, v, nv, r, d, t), it), n, 22)
+    # C3: VMAS, I = 5, expanded masks
+    shape = (4096, 100, 5, 1)
+    r, v, nv, d, t, gam, lp, lm = inputs(shape, f32, 0.01, mask_shape=(4096, 100, 1, 1))
+    n = r.numel()
+    report("C3 [4096x100x5] GAE f32 time_dim=-3 (python entry point)", timeit(lambda: F.generalized_advantage_estimate(0.9, 0.9, v, nv, r, d, t, time_dim=-3), it), n, 22)
+    call = F._prepare_gae(0.9, 0.9, v, nv, r, d, t, -3)
+    st = F.prepare_gae_step(call, normalize=False)
+    report("C3 [4096x100x5] GAE f32 (kernel only)", timeit(st.run, it), n, 22)
+    # C4
+    shape = (65536, 32, 1)
+    r, v, nv, d, t, gam, lp, lm = inputs(shape, f32, 0.01)
+    n = r.numel()
+    call = F._prepare_gae(0.99, 0.95, v, nv, r, d, t, -2)
+    report("C4 [65536x32] GAE f32", timeit(F.prepare_gae_step(call, normalize=False).run, 4 * it), n, 22)
+    report("C4 [65536x32] GAE+normalise f32 (fused)", timeit(F.prepare_gae_step(call, 1e-4, normalize=True).run, 4 * it), n, 22)
+    report("C4 [65536x32] GAE+normalise f32 (scan+normalize kernels)", timeit(F.prepare_gae_step(call, 1e-4, normalize=True, algo=F.ALGO_SCAN).run, 4 * it), n, 22)
+    report("C4 [65536x32] GAE f32 SEQ family", timeit(F.prepare_gae_step(call, normalize=False, algo=F.ALGO_SEQ).run, it), n, 22)
+    # C5
+    shape = (1024, 10000, 1)
+    for dt, nm, b in ((f32, "f32", 4), (f64, "f64", 8)):
+        r, v, nv, d, t, gam, lp, lm = inputs(shape, dt, 0.001)
+        n = r.numel()
+        report(f"C5 [1024x10000] TD(lambda) {nm} tensor gamma", timeit(lambda: F.td_lambda_return_estimate(gam, 0.95, nv, r, d, t), it), n, 3 * b + 2 + b)
+        report(f"C5 [1024x10000] V-trace {nm} tensor gamma", timeit(lambda: F.vtrace_advantage_estimate(gam, lp, lm, v, nv, r, d, t), it), n, 6 * b + 2 + 2 * b)
+        report(f"C5 [1024x10000] GAE {nm} tensor gamma", timeit(lambda: F.generalized_advantage_estimate(gam, 0.95, v, nv, r, d, t), it), n, 4 * b + 2 + 2 * b)
+        report(f"C5 [1024x10000] GAE {nm} scalar gamma", timeit(lambda: F.generalized_advantage_estimate(0.99, 0.95, v, nv, r, d, t), it), n, 3 * b + 2 + 2 * b)
+
+
+if __name__ == "__main__":
+    main()

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kFusedThreads) void gae_fused_kernel(typename Op::A
         i64 start;
         int count;
         geom_of(0, start, count);
-        Op::template load<VEC>(args, start + lane_off, nvalid_of(count), raw[0]);
+        load_inputs<Op, VEC>(args, start + lane_off, nvalid_of(count), raw[0]);
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kFusedThreads) void gae_fused_kernel(typename Op::A
         int count;
         if (k + 1 < K) {
             geom_of(k + 1, start, count);
-            Op::template load<VEC>(args, start + lane_off, nvalid_of(count), raw[(k + 1) & 1]);
+            load_inputs<Op, VEC>(args, start + lane_off, nvalid_of(count), raw[(k + 1) & 1]);
         }
         geom_of(k, start, count);
         const int nvalid = nvalid_of(count);

@@ -113,14 +113,16 @@ __device__ __forceinline__ double exp_t(double x) { return exp(x); }
 
 // ---- per-estimator element logic -------------------------------------------------------------
 // Each Op holds one lane's V consecutive time steps.  Interface used by the scan driver:
-//   Raw / load<VEC>(args, flat, nvalid, raw)   issue the global loads (nothing else: lets the
-//                                              caller prefetch the next chunk)
+//   Raw, for_each_input(args, raw, f)  the input tensors and the lane's V raw elements of each
+//                                   (load_inputs<Op, VEC> issues the global loads and nothing else,
+//                                   which lets the caller prefetch the next chunk)
 //   prepare(args, raw)              fuse the delta / coefficient math
 //   init(e)                         value the recurrence starts from at a row end
 //   step(e, x)                      x_t from x_{t+1}: the reference's exact per-step expression
 //   affine(e, a, b)                 the same step as an affine map (used for aggregates only)
 //   first_value()                   (V-trace) state_value of the lane's first step
-//   store<VEC>(...)                 epilogue + global stores (+ fp64 moments for GAE)
+//   TO, kNumOut, out_ptr(args, k)   the output tensors
+//   outputs(...)                    epilogue: the lane's V output elements (+ fp64 moments for GAE)
 
 template <typename TS_, typename TG_, int V_>
 struct GaeOp {
@@ -138,15 +140,18 @@ struct GaeOp {
     TS v[V];
     TC delta[V], disc[V];
 
-    template <bool VEC>
-    static __device__ __forceinline__ void load(const Args &a, i64 flat, int nvalid, Raw &w) {
-        load_n<VEC>((const TS *)a.reward, flat, nvalid, w.r);
-        load_n<VEC>((const TS *)a.value, flat, nvalid, w.v);
-        load_n<VEC>((const TS *)a.next_value, flat, nvalid, w.nv);
-        load_n<VEC>(a.done, flat, nvalid, w.d);
-        load_n<VEC>(a.terminated, flat, nvalid, w.tm);
-        if (a.gamma_t) load_n<VEC>((const TG *)a.gamma_t, flat, nvalid, w.g);
-        if (a.lg_t) load_n<VEC>((const TG *)a.lg_t, flat, nvalid, w.lg);
+    typedef TS TO;
+    static constexpr int kNumOut = 2;
+    static __device__ __forceinline__ TO *out_ptr(const Args &a, int k) { return (TO *)(k == 0 ? a.advantage : a.value_target); }
+    template <class F>
+    static __device__ __forceinline__ void for_each_input(const Args &a, Raw &w, F &&f) {
+        f((const TS *)a.reward, w.r);
+        f((const TS *)a.value, w.v);
+        f((const TS *)a.next_value, w.nv);
+        f(a.done, w.d);
+        f(a.terminated, w.tm);
+        f((const TG *)a.gamma_t, w.g);   // optional (null -> skipped)
+        f((const TG *)a.lg_t, w.lg);     // optional
     }
     __device__ __forceinline__ void prepare(const Args &a, const Raw &w) {
         const TG gs = (TG)a.gamma, ls = (TG)a.lmbda, lgs = (TG)a.lg;
@@ -178,13 +183,9 @@ struct GaeOp {
             }
         }
     }
-    template <bool VEC>
-    __device__ __forceinline__ void store(const Args &a, i64 flat, int nvalid, const TC (&x)[V], const bool (&)[V],
-                                          TC, TS, double &s, double &ss) const {
-        TS adv[V], vt[V];
-        finish(nvalid, x, adv, vt, s, ss);
-        store_n<VEC>((TS *)a.advantage, flat, nvalid, adv);
-        store_n<VEC>((TS *)a.value_target, flat, nvalid, vt);
+    __device__ __forceinline__ void outputs(int nvalid, const TC (&x)[V], const bool (&)[V], TC, TS, TO (&o0)[V],
+                                            TO (&o1)[V], double &s, double &ss) const {
+        finish(nvalid, x, o0, o1, s, ss);
     }
 };
 
@@ -204,14 +205,17 @@ struct TdLambdaOp {
     TS r[V], nvm[V], dn[V], omd[V];
     TG gm[V], lm[V];
 
-    template <bool VEC>
-    static __device__ __forceinline__ void load(const Args &a, i64 flat, int nvalid, Raw &w) {
-        load_n<VEC>((const TS *)a.reward, flat, nvalid, w.r);
-        load_n<VEC>((const TS *)a.next_value, flat, nvalid, w.nv);
-        load_n<VEC>(a.done, flat, nvalid, w.d);
-        load_n<VEC>(a.terminated, flat, nvalid, w.tm);
-        if (a.gamma_t) load_n<VEC>((const TG *)a.gamma_t, flat, nvalid, w.g);
-        if (a.lmbda_t) load_n<VEC>((const TG *)a.lmbda_t, flat, nvalid, w.l);
+    typedef TS TO;
+    static constexpr int kNumOut = 1;
+    static __device__ __forceinline__ TO *out_ptr(const Args &a, int) { return (TO *)a.returns; }
+    template <class F>
+    static __device__ __forceinline__ void for_each_input(const Args &a, Raw &w, F &&f) {
+        f((const TS *)a.reward, w.r);
+        f((const TS *)a.next_value, w.nv);
+        f(a.done, w.d);
+        f(a.terminated, w.tm);
+        f((const TG *)a.gamma_t, w.g);   // optional
+        f((const TG *)a.lmbda_t, w.l);   // optional
     }
     __device__ __forceinline__ void prepare(const Args &a, const Raw &w) {
 #pragma unroll
@@ -238,13 +242,10 @@ struct TdLambdaOp {
     }
     __device__ __forceinline__ TS first_value() const { return (TS)0; }
 
-    template <bool VEC>
-    __device__ __forceinline__ void store(const Args &a, i64 flat, int nvalid, const TC (&x)[V], const bool (&)[V],
-                                          TC, TS, double &, double &) const {
-        TS out[V];
+    __device__ __forceinline__ void outputs(int, const TC (&x)[V], const bool (&)[V], TC, TS, TO (&o0)[V], TO (&)[V],
+                                            double &, double &) const {
 #pragma unroll
-        for (int e = 0; e < V; ++e) out[e] = (TS)x[e];
-        store_n<VEC>((TS *)a.returns, flat, nvalid, out);
+        for (int e = 0; e < V; ++e) o0[e] = (TS)x[e];
     }
 };
 
@@ -265,16 +266,19 @@ struct VtraceOp {
     TG td[V];
     TC coef[V], delta[V];
 
-    template <bool VEC>
-    static __device__ __forceinline__ void load(const Args &a, i64 flat, int nvalid, Raw &w) {
-        load_n<VEC>((const TS *)a.log_pi, flat, nvalid, w.lp);
-        load_n<VEC>((const TS *)a.log_mu, flat, nvalid, w.lmu);
-        load_n<VEC>((const TS *)a.value, flat, nvalid, w.v);
-        load_n<VEC>((const TS *)a.next_value, flat, nvalid, w.nv);
-        load_n<VEC>((const TS *)a.reward, flat, nvalid, w.r);
-        load_n<VEC>(a.done, flat, nvalid, w.d);
-        load_n<VEC>(a.terminated, flat, nvalid, w.tm);
-        if (a.gamma_t) load_n<VEC>((const TG *)a.gamma_t, flat, nvalid, w.g);
+    typedef TC TO;
+    static constexpr int kNumOut = 2;
+    static __device__ __forceinline__ TO *out_ptr(const Args &a, int k) { return (TO *)(k == 0 ? a.advantage : a.vs); }
+    template <class F>
+    static __device__ __forceinline__ void for_each_input(const Args &a, Raw &w, F &&f) {
+        f((const TS *)a.log_pi, w.lp);
+        f((const TS *)a.log_mu, w.lmu);
+        f((const TS *)a.value, w.v);
+        f((const TS *)a.next_value, w.nv);
+        f((const TS *)a.reward, w.r);
+        f(a.done, w.d);
+        f(a.terminated, w.tm);
+        f((const TG *)a.gamma_t, w.g);   // optional
     }
     __device__ __forceinline__ void prepare(const Args &a, const Raw &w) {
         const TS rho_hi = (TS)a.rho_thresh, c_hi = (TS)a.c_thresh;
@@ -300,10 +304,8 @@ struct VtraceOp {
 
     // x_next / v_next: x and state_value of the step that follows the lane's last step
     // (only read when that step is not a row end).
-    template <bool VEC>
-    __device__ __forceinline__ void store(const Args &a, i64 flat, int nvalid, const TC (&x)[V], const bool (&row_end)[V],
-                                          TC x_next, TS v_next, double &, double &) const {
-        TC adv[V], vs[V];
+    __device__ __forceinline__ void outputs(int nvalid, const TC (&x)[V], const bool (&row_end)[V], TC x_next, TS v_next,
+                                            TO (&adv)[V], TO (&vs)[V], double &, double &) const {
         TC vs_next = x_next + (TC)v_next;
 #pragma unroll
         for (int e = V - 1; e >= 0; --e) {
@@ -312,10 +314,22 @@ struct VtraceOp {
             adv[e] = (TC)crho[e] * (((TC)r[e] + (TC)td[e] * nxt) - (TC)v[e]);
             if (e < nvalid) vs_next = vs[e];
         }
-        store_n<VEC>((TC *)a.advantage, flat, nvalid, adv);
-        store_n<VEC>((TC *)a.vs, flat, nvalid, vs);
     }
 };
+
+// ---- generic load / store over an Op's tensor lists ------------------------------------------------
+template <class Op, bool VEC>
+__device__ __forceinline__ void load_inputs(const typename Op::Args &a, i64 flat, int nvalid, typename Op::Raw &w) {
+    Op::for_each_input(a, w, [&](auto *base, auto &dst) {
+        if (base) load_n<VEC>(base, flat, nvalid, dst);
+    });
+}
+template <class Op, bool VEC>
+__device__ __forceinline__ void store_outputs(const typename Op::Args &a, i64 flat, int nvalid,
+                                              const typename Op::TO (&o0)[Op::V], const typename Op::TO (&o1)[Op::V]) {
+    store_n<VEC>(Op::out_ptr(a, 0), flat, nvalid, o0);
+    if (Op::kNumOut > 1) store_n<VEC>(Op::out_ptr(a, 1), flat, nvalid, o1);
+}
 
 // ---- scan of one chunk by one team (kWaves waves) ---------------------------------------------
 template <class Op>

@@ -27,6 +27,8 @@
 //
 // HBM traffic = algorithmic bytes: each input element is read once, each output written
 // once (GAE fp32 22 B / transition); per-block {sum, sumsq} partials add 16 B per block.
+#include <type_traits>
+
 #include "scan_core.h"
 
 namespace {
@@ -78,13 +80,13 @@ __global__ __launch_bounds__(kShortThreads) void scan_short_kernel(typename Op::
     i64 start;
     int count;
     geom_of(0, start, count);
-    Op::template load<VEC>(args, start + lane_off, clamp_nvalid(count, lane_off, V), cur);
+    load_inputs<Op, VEC>(args, start + lane_off, clamp_nvalid(count, lane_off, V), cur);
     for (i64 it = 0; it < niter; ++it) {
         if (it + 1 < niter) {
             i64 nstart;
             int ncount;
             geom_of(it + 1, nstart, ncount);
-            Op::template load<VEC>(args, nstart + lane_off, clamp_nvalid(ncount, lane_off, V), nxt);
+            load_inputs<Op, VEC>(args, nstart + lane_off, clamp_nvalid(ncount, lane_off, V), nxt);
         }
         geom_of(it, start, count);
         const int nvalid = clamp_nvalid(count, lane_off, V);
@@ -95,12 +97,142 @@ __global__ __launch_bounds__(kShortThreads) void scan_short_kernel(typename Op::
         TS Xv = (TS)0;
         scan_chunk<Op, WAVE_INDEP>(op, sh[team], (int)(it & 1), nvalid, (unsigned)lane_off % T, T, geo.scan_lanes, Xc, Xv,
                                    [&](const TC(&xs)[V], const bool(&row_end)[V], TC x_in, TS v_next) {
-                                       op.template store<VEC>(args, flat, nvalid, xs, row_end, x_in, v_next, s, ss);
+                                       typename Op::TO o0[V], o1[V];
+                                       op.outputs(nvalid, xs, row_end, x_in, v_next, o0, o1, s, ss);
+                                       store_outputs<Op, VEC>(args, flat, nvalid, o0, o1);
                                    });
         cur = nxt;
     }
     if (partials) {
         block_sum2<kShortThreads>(s, ss, red);
+        if (threadIdx.x == 0) {
+            partials[2 * (i64)blockIdx.x] = s;
+            partials[2 * (i64)blockIdx.x + 1] = ss;
+        }
+    }
+}
+
+
+// ---- SHORT rows with feature dims (I > 1, T*I <= chunk) -------------------------------------------
+// Element (o, t, i) sits at (o*T + t)*I + i: the I scans of one outer row are interleaved in
+// memory.  A team takes a chunk of RO whole outer rows (one contiguous byte range per tensor),
+// loads it with the same coalesced 16-byte loads as the I == 1 kernels, and transposes it through
+// LDS so that every lane ends up holding V consecutive time steps of ONE (o, i) row: the chunk
+// then looks exactly like RO*I time-contiguous rows of length T and goes through the same
+// scan_chunk.  Outputs take the inverse route (LDS scatter, coalesced 16-byte stores), so HBM
+// traffic stays at the algorithmic bytes.
+template <class Op, bool VEC, bool WAVE_INDEP>
+__global__ __launch_bounds__(kTeam) void scan_interleaved_kernel(typename Op::Args args, ScanGeom geo, int I, double *partials) {
+    typedef typename Op::TC TC;
+    typedef typename Op::TS TS;
+    typedef typename Op::TO TO;
+    constexpr int V = Op::V;
+    constexpr int CH = kTeam * V;
+    __shared__ __align__(16) unsigned char lds_in[sizeof(typename Op::Raw) * kTeam];
+    __shared__ __align__(16) TO lds_out[Op::kNumOut][CH];
+    __shared__ TeamShared<Op> sh;
+    __shared__ double red[2 * kWaves];
+    const int lane_off = (int)threadIdx.x * V;
+    const unsigned T = (unsigned)geo.T;
+    const i64 row_elems = geo.T * I;  // elements of one outer row
+
+    // virtual (row-major per (o,i)) position of this lane's first element inside a chunk, and the
+    // physical in-chunk offset of each of its V elements
+    int pe[V];
+    {
+        unsigned rv = (unsigned)lane_off / T, t = (unsigned)lane_off % T;
+        unsigned ol = rv / (unsigned)I, i = rv % (unsigned)I;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            pe[e] = (int)((ol * T + t) * (unsigned)I + i);
+            if (++t == T) { t = 0; if (++i == (unsigned)I) { i = 0; ++ol; } }
+        }
+    }
+    const unsigned t0 = (unsigned)lane_off % T;
+
+    auto geom_of = [&](i64 c, i64 &start, int &count) {
+        const i64 row0 = c * geo.rows_per_chunk;
+        i64 nrows = c < geo.nchunks ? geo.O - row0 : 0;
+        if (nrows > geo.rows_per_chunk) nrows = geo.rows_per_chunk;
+        if (nrows < 0) nrows = 0;
+        start = row0 * row_elems;
+        count = (int)(nrows * row_elems);
+    };
+
+    double s = 0.0, ss = 0.0;
+    typename Op::Raw cur, nxt;
+    i64 start;
+    int count;
+    const i64 niter = (geo.nchunks + gridDim.x - 1) / gridDim.x;
+    geom_of(blockIdx.x, start, count);
+    load_inputs<Op, VEC>(args, start + lane_off, clamp_nvalid(count, lane_off, V), cur);
+    for (i64 it = 0; it < niter; ++it) {
+        const i64 c = it * gridDim.x + blockIdx.x;
+        if (it + 1 < niter) {
+            i64 nstart;
+            int ncount;
+            geom_of(c + gridDim.x, nstart, ncount);
+            load_inputs<Op, VEC>(args, nstart + lane_off, clamp_nvalid(ncount, lane_off, V), nxt);
+        }
+        geom_of(c, start, count);
+        const int nvalid = clamp_nvalid(count, lane_off, V);
+        // stage the chunk in LDS in memory order, then gather this lane's (o,i)-row elements
+        {
+            size_t off = 0;
+            Op::for_each_input(args, cur, [&](auto *base, auto &arr) {
+                typedef typename std::remove_reference<decltype(arr[0])>::type E;
+                if (base) {
+                    E *dst = (E *)(lds_in + off) + lane_off;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) dst[e] = arr[e];
+                }
+                off += sizeof(E) * CH;
+            });
+        }
+        __syncthreads();
+        typename Op::Raw vraw;
+        {
+            size_t off = 0;
+            Op::for_each_input(args, vraw, [&](auto *base, auto &arr) {
+                typedef typename std::remove_reference<decltype(arr[0])>::type E;
+                if (base) {
+                    const E *src = (const E *)(lds_in + off);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) arr[e] = e < nvalid ? src[pe[e]] : (E)0;
+                }
+                off += sizeof(E) * CH;
+            });
+        }
+        Op op;
+        op.prepare(args, vraw);
+        TC Xc = (TC)0;
+        TS Xv = (TS)0;
+        scan_chunk<Op, WAVE_INDEP>(op, sh, (int)(it & 1), nvalid, t0, T, geo.scan_lanes, Xc, Xv,
+                                   [&](const TC(&xs)[V], const bool(&row_end)[V], TC x_in, TS v_next) {
+                                       TO o0[V], o1[V];
+                                       op.outputs(nvalid, xs, row_end, x_in, v_next, o0, o1, s, ss);
+#pragma unroll
+                                       for (int e = 0; e < V; ++e) {
+                                           if (e < nvalid) {
+                                               lds_out[0][pe[e]] = o0[e];
+                                               if (Op::kNumOut > 1) lds_out[Op::kNumOut - 1][pe[e]] = o1[e];
+                                           }
+                                       }
+                                   });
+        __syncthreads();
+        {
+            TO o0[V], o1[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                o0[e] = lds_out[0][lane_off + e];
+                o1[e] = lds_out[Op::kNumOut - 1][lane_off + e];
+            }
+            store_outputs<Op, VEC>(args, start + lane_off, nvalid, o0, o1);
+        }
+        cur = nxt;
+    }
+    if (partials) {
+        block_sum2<kTeam>(s, ss, red);
         if (threadIdx.x == 0) {
             partials[2 * (i64)blockIdx.x] = s;
             partials[2 * (i64)blockIdx.x + 1] = ss;
@@ -130,7 +262,7 @@ __global__ __launch_bounds__(kLongThreads) void scan_long_kernel(typename Op::Ar
     int c = nchunks - 1;
     typename Op::Raw cur, nxt;
     if (row < geo.O)
-        Op::template load<VEC>(args, row * geo.T + (i64)c * kChunk + lane_off, clamp_nvalid(chunk_count(c), lane_off, V), cur);
+        load_inputs<Op, VEC>(args, row * geo.T + (i64)c * kChunk + lane_off, clamp_nvalid(chunk_count(c), lane_off, V), cur);
     TC Xc = (TC)0;
     TS Xv = (TS)0;
     while (row < geo.O) {
@@ -138,7 +270,7 @@ __global__ __launch_bounds__(kLongThreads) void scan_long_kernel(typename Op::Ar
         int nc = c - 1;
         if (nc < 0) { nrow = row + gridDim.x; nc = nchunks - 1; }
         if (nrow < geo.O)
-            Op::template load<VEC>(args, nrow * geo.T + (i64)nc * kChunk + lane_off,
+            load_inputs<Op, VEC>(args, nrow * geo.T + (i64)nc * kChunk + lane_off,
                                    clamp_nvalid(chunk_count(nc), lane_off, V), nxt);
         const i64 start = row * geo.T + (i64)c * kChunk;
         const int nvalid = clamp_nvalid(chunk_count(c), lane_off, V);
@@ -147,7 +279,9 @@ __global__ __launch_bounds__(kLongThreads) void scan_long_kernel(typename Op::Ar
         op.prepare(args, cur);
         scan_chunk<Op, false>(op, sh, buf, nvalid, (unsigned)((i64)c * kChunk + lane_off), T, kWave, Xc, Xv,
                               [&](const TC(&xs)[V], const bool(&row_end)[V], TC x_in, TS v_next) {
-                                  op.template store<VEC>(args, flat, nvalid, xs, row_end, x_in, v_next, s, ss);
+                                  typename Op::TO o0[V], o1[V];
+                                  op.outputs(nvalid, xs, row_end, x_in, v_next, o0, o1, s, ss);
+                                  store_outputs<Op, VEC>(args, flat, nvalid, o0, o1);
                               });
         buf ^= 1;
         cur = nxt;
@@ -166,7 +300,7 @@ __global__ __launch_bounds__(kLongThreads) void scan_long_kernel(typename Op::Ar
 // ---- host side ----------------------------------------------------------------------------------
 struct Plan {
     bool ok;
-    bool long_rows, wave_indep, vec;
+    bool long_rows, wave_indep, vec, interleaved;
     int rows_per_chunk;
     i64 nchunks;
     i64 nblocks;
@@ -192,8 +326,27 @@ int device_cus() {
 // V: elements per lane; ptr_align_ok: every tensor base pointer is 16-byte aligned.
 Plan make_plan(i64 O, i64 T, i64 I, int V, bool ptr_align_ok, int cus) {
     Plan p{};
-    if (I != 1 || T >= (1LL << 31) - 4096) return p;  // not this family's shape
     const i64 chunk = (i64)kTeam * V;
+    if (I > 1) {
+        // interleaved feature dims: whole outer rows must fit a chunk
+        if (T * I > chunk || I > 1024) return p;
+        i64 R = chunk / (T * I);
+        const i64 q = V / gcd_i64(T * I, V);
+        if (R >= q) R -= R % q;
+        if (R > O) R = O;
+        p.ok = true;
+        p.interleaved = true;
+        p.rows_per_chunk = (int)R;
+        p.nchunks = (O + R - 1) / R;
+        i64 nb = p.nchunks;
+        if (nb > (i64)cus * 4) nb = (i64)cus * 4;
+        if (nb > 4096) nb = 4096;  // ~4 resident teams per CU, chunks walked grid-stride
+        p.nblocks = nb;
+        p.vec = ptr_align_ok && (p.nchunks == 1 || (R * T * I) % V == 0);
+        p.wave_indep = ((i64)kWave * V) % T == 0;
+        return p;
+    }
+    if (T >= (1LL << 31) - 4096) return p;  // not this family's shape
     p.ok = true;
     if (T <= chunk) {
         // R whole rows per chunk; prefer R*T multiple of V so every chunk start stays aligned
@@ -220,11 +373,16 @@ Plan make_plan(i64 O, i64 T, i64 I, int V, bool ptr_align_ok, int cus) {
 }
 
 template <class Op>
-LaunchResult launch_scan(hipStream_t s, const typename Op::Args &a, const Plan &p, i64 O, i64 T, double *partials,
+LaunchResult launch_scan(hipStream_t s, const typename Op::Args &a, const Plan &p, i64 O, i64 T, i64 I, double *partials,
                          const char *name) {
     ScanGeom geo{O, T, p.rows_per_chunk, scan_lanes_for(T, Op::V, p.wave_indep), p.nchunks};
     const dim3 grid((unsigned)p.nblocks);
-    if (p.long_rows) {
+    if (p.interleaved) {
+#define TRL_LAUNCH(VEC, WI) hipLaunchKernelGGL((scan_interleaved_kernel<Op, VEC, WI>), grid, dim3(kTeam), 0, s, a, geo, (int)I, partials)
+        if (p.wave_indep) { if (p.vec) TRL_LAUNCH(true, true); else TRL_LAUNCH(false, true); }
+        else              { if (p.vec) TRL_LAUNCH(true, false); else TRL_LAUNCH(false, false); }
+#undef TRL_LAUNCH
+    } else if (p.long_rows) {
         if (p.vec) hipLaunchKernelGGL((scan_long_kernel<Op, true>), grid, dim3(kLongThreads), 0, s, a, geo, partials);
         else hipLaunchKernelGGL((scan_long_kernel<Op, false>), grid, dim3(kLongThreads), 0, s, a, geo, partials);
     } else {
@@ -252,7 +410,7 @@ LaunchResult dispatch_scan(int vdt, int cdt, F &&f) {
 
 i64 scan_max_partials(i64 O, i64 T, i64 I) {
     (void)O; (void)T; (void)I;
-    return kMaxLongGrid > kMaxShortGrid ? kMaxLongGrid : kMaxShortGrid;
+    return 4096;  // >= every grid this file launches (LONG <= 2048, SHORT <= 512, interleaved <= 4 * #CUs)
 }
 
 LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a) {
@@ -263,7 +421,8 @@ LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a) 
         typedef decltype(op) Op;
         Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus());
         if (!p.ok) return LaunchResult{2, 0, nullptr};
-        return launch_scan<Op>(s, a, p, a.O, a.T, a.partials, p.long_rows ? "gae_scan_long" : "gae_scan_short");
+        return launch_scan<Op>(s, a, p, a.O, a.T, a.I, a.partials,
+                               p.interleaved ? "gae_scan_interleaved" : p.long_rows ? "gae_scan_long" : "gae_scan_short");
     });
 }
 
@@ -274,7 +433,8 @@ LaunchResult launch_td_lambda_scan(hipStream_t s, int vdt, int cdt, const TdLamb
         typedef decltype(op) Op;
         Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus());
         if (!p.ok) return LaunchResult{2, 0, nullptr};
-        return launch_scan<Op>(s, a, p, a.O, a.T, nullptr, p.long_rows ? "td_lambda_scan_long" : "td_lambda_scan_short");
+        return launch_scan<Op>(s, a, p, a.O, a.T, a.I, nullptr,
+                               p.interleaved ? "td_lambda_scan_interleaved" : p.long_rows ? "td_lambda_scan_long" : "td_lambda_scan_short");
     });
 }
 
@@ -286,6 +446,7 @@ LaunchResult launch_vtrace_scan(hipStream_t s, int vdt, int cdt, const VtraceArg
         typedef decltype(op) Op;
         Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus());
         if (!p.ok) return LaunchResult{2, 0, nullptr};
-        return launch_scan<Op>(s, a, p, a.O, a.T, nullptr, p.long_rows ? "vtrace_scan_long" : "vtrace_scan_short");
+        return launch_scan<Op>(s, a, p, a.O, a.T, a.I, nullptr,
+                               p.interleaved ? "vtrace_scan_interleaved" : p.long_rows ? "vtrace_scan_long" : "vtrace_scan_short");
     });
 }

@@ -441,7 +441,7 @@ def prepare_gae_step(call: _GaeCall, eps: Optional[float] = None, *, normalize: 
     adv = torch.empty(call.shape, dtype=call.vdt, device=dev)
     vt = torch.empty(call.shape, dtype=call.vdt, device=dev)
     ws = _workspace(lib, dev, call.O, call.T, call.I)
-    stats = torch.empty(3, dtype=torch.float64, device=dev) if (want_stats or not normalize) else None
+    stats = torch.empty(3, dtype=torch.float64, device=dev) if want_stats else None
     head = (_stream(dev), _DT[call.vdt], _DT[call.cdt], _ptr(call.reward), _ptr(call.value), _ptr(call.next_value),
             _ptr(call.done), _ptr(call.terminated), _ptr(call.gamma_t), _ptr(call.lg_t), call.gamma, call.lmbda, call.lg,
             call.O, call.T, call.I, _ptr(adv), _ptr(vt))
