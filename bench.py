@@ -3,11 +3,12 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 One "step" is one pass of the hot path over one batch of synthetic rollouts already resident in
-HBM: trl_gae_fwd (fused delta + scan + value_target + fp64 moments) -> [N > 1: one RCCL
-all-reduce of the 3 fp64 moments] -> trl_normalize (in place).  Every rank owns a full
-[65536 x 32] batch (weak scaling: the env dimension is sharded, nothing else is exchanged).
-Rank 0 prints ONE JSON line (schema in the task contract) with `roofline` for the dominant
-kernel (the GAE scan) and `cpu_baseline` (the CPU oracle timed on this host, N = 1 only).
+HBM.  N = 1: trl_gae_normalize_fwd -- ONE launch (fused delta + scan + value_target + fp64 moments
++ in-launch gather + normalisation).  N > 1: trl_gae_fwd (scan + moments) -> one RCCL all-reduce of
+the 3 fp64 moments -> trl_normalize (in place).  Every rank owns a full [65536 x 32] batch (weak
+scaling: the env dimension is sharded, nothing else is exchanged).  Rank 0 prints ONE JSON line
+(schema in the task contract) with `roofline` for the dominant kernel and `cpu_baseline` (the CPU
+oracle timed on this host, N = 1 only).
 """
 from __future__ import annotations
 
@@ -28,6 +29,10 @@ O_ENVS, T_STEPS = 65536, 32
 GAMMA, LMBDA, EPS = 0.99, 0.95, 1e-4
 BYTES_PER_TRANSITION = 22  # fp32 GAE: 3x4 B + 2x1 B read, 2x4 B written; normalise adds no compulsory traffic
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+# HBM bytes per launch of the fused kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+# passes, FETCH_SIZE x2 as the guide prescribes for gfx950): profiles/r01_d_bench_pmc_hbm_traffic.json.  A counter
+# pass cannot run inside the timed bench, so the measured figure is carried here; null for the unprofiled N > 1 path.
+PMC_TRAFFIC_BYTES_FUSED = 46666451
 
 
 def make_inputs(dev, seed):
@@ -159,7 +164,8 @@ def main():
                        "per_gpu_transitions": n_trans, "parallelism": f"env-sharded x{world}",
                        "collective": "all_reduce(3 x f64)" if dist else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kernel_name,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": PMC_TRAFFIC_BYTES_FUSED if kernel_name == "gae_fused" else None, "kernel": kernel_name,
                          "kernel_ms": gae_ms, "bytes_per_launch": n_trans * BYTES_PER_TRANSITION,
                          "host_enqueue_ms_per_step": t_host / args.steps * 1e3},
         }

@@ -520,6 +520,23 @@ def normalize_(x: torch.Tensor, stats: torch.Tensor, eps: float, out: Optional[t
     return out
 
 
+def stats_to_mean_std(stats: torch.Tensor, dtype: torch.dtype, eps: float) -> Tuple[float, float]:
+    """Host restatement of what ``trl_normalize`` derives from ``{N, sum, sumsq}``: mean and unbiased
+    std rounded to ``dtype``, std clamped from below by ``eps`` (NaN kept).  For tests / logging; reads
+    ``stats`` on the host."""
+    n, s, ss = (float(v) for v in stats.detach().cpu().tolist())
+    mean = s / n
+    var = (ss - n * mean * mean) / (n - 1.0) if n > 1 else float("nan")
+    if var < 0.0:
+        var = 0.0
+    mean_s = _round_to(mean, dtype)
+    std_s = _round_to(math.sqrt(var), dtype) if var == var else float("nan")
+    eps_s = _round_to(eps, dtype)
+    if std_s < eps_s:
+        std_s = eps_s
+    return mean_s, std_s
+
+
 def standardize(x: torch.Tensor, eps: float, group=None, distributed: bool = False) -> torch.Tensor:
     """Out-of-place ``(x - mean) / std.clamp_min(eps)`` over all elements.  With ``distributed``
     (or an explicit process ``group``) the fp64 moments are all-reduced first -- one 24-byte RCCL
