@@ -9,10 +9,10 @@
 constexpr i64 N = 65536LL * 32;
 typedef GaeOp<float, float, 4> Op;
 
-template <int ABL, int K>
+template <int ABL, int K, int TEAMS = 4>
 void run(const char* name, GaeArgs a, FusedGeom geo, FusedWs* ws, int G, int iters, double* sink = nullptr) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    auto f = [&] { hipLaunchKernelGGL((gae_fused_kernel<Op, true, true, K, ABL>), dim3(G), dim3(kFusedThreads), 0, 0, a, geo, ws, sink); };
+    auto f = [&] { hipLaunchKernelGGL((gae_fused_kernel<Op, true, true, K, ABL, TEAMS>), dim3(G), dim3(TEAMS * 256), 0, 0, a, geo, ws, sink); };
     for (int i = 0; i < 20; ++i) f();
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
@@ -20,7 +20,7 @@ void run(const char* name, GaeArgs a, FusedGeom geo, FusedWs* ws, int G, int ite
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     double us = ms * 1e3 / iters;
-    printf("%-40s G=%d K=%d %8.2f us/launch  %8.1f GB/s\n", name, G, K, us, N * 22.0 / us * 1e-3);
+    printf("%-40s G=%d K=%d teams=%d %8.2f us/launch  %8.1f GB/s\n", name, G, K, TEAMS, us, N * 22.0 / us * 1e-3);
 }
 
 int main() {
@@ -36,6 +36,11 @@ int main() {
     const int G = 256;
     FusedGeom geo{65536, 32, 32, 8, 65536 / 32, (double)N, 1e-4, 2};
     run<0, 2>("full", a, geo, ws, G, 300);
+    run<0, 4, 2>("full", a, geo, ws, G, 300);
+    run<0, 2, 2>("full", a, geo, ws, 512, 300);
+    run<0, 4, 1>("full", a, geo, ws, 512, 300);
+    run<5, 4, 2>("plain scan", a, geo, ws, G, 300);
+    run<5, 2, 2>("plain scan", a, geo, ws, 512, 300);
     run<1, 2>("no gather", a, geo, ws, G, 300);
     run<2, 2>("no gather, no block reduce", a, geo, ws, G, 300);
     run<3, 2>("no gather/reduce/scan steps", a, geo, ws, G, 300);

@@ -61,15 +61,15 @@ __device__ __forceinline__ double untag(unsigned long long b) { return __longlon
 // ABL (development only, tools/kbench): 0 = product; 1 = skip the gather (own block's moments);
 // 2 = also skip the block reduction; 3 = also skip the wave scan steps; 4 = product without the
 // deferred store of the last chunk's value_target.
-template <class Op, bool VEC, bool WAVE_INDEP, int K, int ABL = 0>
-__global__ __launch_bounds__(kFusedThreads) void gae_fused_kernel(typename Op::Args args, FusedGeom geo, FusedWs *ws,
+template <class Op, bool VEC, bool WAVE_INDEP, int K, int ABL = 0, int TEAMS = kTeams>
+__global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::Args args, FusedGeom geo, FusedWs *ws,
                                                                   double *stats_out) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
     constexpr int V = Op::V;
-    constexpr int NW = kFusedThreads / kWave;
+    constexpr int NW = TEAMS * kTeam / kWave;
     constexpr bool kDeferVt = ABL != 4;
-    __shared__ TeamShared<Op> sh[kTeams];
+    __shared__ TeamShared<Op> sh[TEAMS];
     __shared__ double red[2 * NW];
     __shared__ double bc[3];
 
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kFusedThreads) void gae_fused_kernel(typename Op::A
     i64 flat_k[K];
     int nvalid_k[K];
 
-    auto chunk_of = [&](int k) { return ((i64)k * gridDim.x + blockIdx.x) * kTeams + team; };
+    auto chunk_of = [&](int k) { return ((i64)k * gridDim.x + blockIdx.x) * TEAMS + team; };
     auto geom_of = [&](int k, i64 &start, int &count) {
         const i64 c = chunk_of(k);
         const i64 row0 = c * geo.rows_per_chunk;

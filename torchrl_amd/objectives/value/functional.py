@@ -228,7 +228,7 @@ def _needs_grad(*xs) -> bool:
 
 
 _GRAD_MSG = (
-    "torchrl_amd: differentiating through {} is not implemented yet (forward HIP kernels only); "
+    "torchrl_amd: differentiating through {} is not implemented yet (GAE and TD(lambda) are); "
     "call it under torch.no_grad() / with differentiable=False, or detach the inputs."
 )
 
@@ -358,6 +358,105 @@ def _launch_gae_normalize(c: _GaeCall, eps: float, algo: int = ALGO_AUTO, out=No
     return adv, vt, stats
 
 
+
+# ---------------------------------------------------------------------------------------------
+# autograd: the adjoint of a reverse affine scan is a forward scan with the same coefficients
+# ---------------------------------------------------------------------------------------------
+# Forward x_t = b_t + a_t x_{t+1}  =>  G_t = dL/db_t = gbar_t + a_{t-1} G_{t-1}, G_{-1} = 0.  In the
+# time-reversed index u = T-1-t this is again a reverse scan, G'_u = gbar'_u + a'_{u+1} G'_{u+1}, so the
+# backward pass runs on the SAME HIP kernels (trl_gae_fwd with value = next_value = 0 and every step
+# "terminated", which makes delta = gbar' exactly) on flipped inputs with the masks shifted by one
+# step.  Gradients flow to reward / state_value / next_state_value (reference behaviour under
+# differentiable=True, test/test_cost.py:15521-15584); gamma / lmbda tensors that require grad are
+# not supported.  V-trace has no backward here yet.
+def _adjoint_scan(gbar3: torch.Tensor, done3: torch.Tensor, lg3: Optional[torch.Tensor], lg: float, cdt) -> torch.Tensor:
+    """G (O,T,I) from gbar (O,T,I): G_t = gbar_t + (lg_{t-1} * (1-done_{t-1})) * G_{t-1}."""
+    O, T, I = gbar3.shape
+    dev = gbar3.device
+    gb = gbar3.flip(1).contiguous()
+    dflip = done3.flip(1)
+    dshift = torch.cat([dflip[:, 1:], torch.ones_like(dflip[:, :1])], 1).contiguous()
+    lgs = None
+    if lg3 is not None:
+        lf = lg3.flip(1)
+        lgs = torch.cat([lf[:, 1:], torch.zeros_like(lf[:, :1])], 1).contiguous()
+    zeros = torch.zeros_like(gb)
+    call = _GaeCall(shape=(O, T, I), O=O, T=T, I=I, vdt=gb.dtype, cdt=cdt, out_dtype=gb.dtype, reward=gb, value=zeros,
+                    next_value=zeros, done=dshift, terminated=torch.ones_like(dshift), gamma_t=lgs, lg_t=lgs,
+                    gamma=0.0, lmbda=0.0, lg=lg)
+    G, _, _ = _launch_gae(call)
+    return G.flip(1)
+
+
+class _GaeFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, state_value, next_state_value, reward, call, normalize_eps):
+        if normalize_eps is None:
+            adv, vt, _ = _launch_gae(call)
+        else:
+            raise NotImplementedError("differentiable normalised GAE: normalise the differentiable advantage with torch ops")
+        ctx.call = call
+        ctx.in_dtypes = (state_value.dtype, next_state_value.dtype, reward.dtype)
+        ctx.in_shapes = (state_value.shape, next_state_value.shape, reward.shape)
+        return adv, vt
+
+    @staticmethod
+    def backward(ctx, g_adv, g_vt):
+        c = ctx.call
+        shp3 = (c.O, c.T, c.I)
+        dt = torch.promote_types(c.vdt, c.cdt)
+        z = lambda g: torch.zeros(shp3, dtype=dt, device=c.reward.device) if g is None else g.to(dt).contiguous().view(shp3)
+        ga, gv = z(g_adv), z(g_vt)
+        done3 = c.done.view(shp3)
+        lg3 = None
+        if c.gamma_t is not None:
+            lg3 = (c.lg_t if c.lg_t is not None else c.gamma_t * _round_to(c.lmbda, c.cdt)).view(shp3).to(dt)
+        G = _adjoint_scan(ga + gv, done3, lg3, c.lg, c.cdt if dt == c.cdt else dt)
+        nt = (1 - c.terminated.view(shp3)).to(dt)
+        g_coef = c.gamma_t.view(shp3).to(dt) * nt if c.gamma_t is not None else nt * c.gamma
+        outs = (gv - G, G * g_coef, G)
+        return tuple(o.to(d).view(s) for o, d, s in zip(outs, ctx.in_dtypes, ctx.in_shapes)) + (None, None)
+
+
+class _TdLambdaFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, next_state_value, reward, call, out_dtype):
+        ctx.call = call
+        ctx.in_dtypes = (next_state_value.dtype, reward.dtype)
+        ctx.in_shapes = (next_state_value.shape, reward.shape)
+        return _launch_td_lambda(call, out_dtype)
+
+    @staticmethod
+    def backward(ctx, g_ret):
+        c = ctx.call
+        if not c.rolling:
+            raise NotImplementedError("backward of td_lambda_return_estimate(rolling_gamma=False) is not implemented")
+        shp3 = (c.O, c.T, c.I)
+        dt = torch.promote_types(c.vdt, c.cdt)
+        dev = c.reward.device
+        gr = g_ret.to(dt).contiguous().view(shp3)
+        done3 = c.done.view(shp3)
+        dn = done3.to(dt)
+        gam = c.gamma_t.view(shp3).to(dt) if c.gamma_t is not None else torch.full((), c.gamma, dtype=dt, device=dev)
+        lam = c.lmbda_t.view(shp3).to(dt) if c.lmbda_t is not None else torch.full((), c.lmbda, dtype=dt, device=dev)
+        tensor_coef = c.gamma_t is not None or c.lmbda_t is not None
+        lg3 = (gam * lam).expand(shp3).contiguous() if tensor_coef else None
+        G = _adjoint_scan(gr, done3, lg3, float(c.gamma * c.lmbda), dt)
+        # R_t = r_t + gamma_t((1-lmbda_t) v'_t + lmbda_t (g_{t+1} nd_t + v'_t d_t)); g_T := v'_{T-1}
+        d_nvm = G * gam * ((1 - lam) + lam * dn)
+        last = (G * gam * lam * (1 - dn))[:, -1]
+        d_nvm = torch.cat([d_nvm[:, :-1], (d_nvm[:, -1] + last).unsqueeze(1)], 1)
+        d_nv = d_nvm * (1 - c.terminated.view(shp3)).to(dt)
+        outs = (d_nv, G)
+        return tuple(o.to(d).view(s) for o, d, s in zip(outs, ctx.in_dtypes, ctx.in_shapes)) + (None, None)
+
+
+def _no_coef_grad(name, *coefs):
+    for x in coefs:
+        if isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError(f"torchrl_amd: {name}: gradients w.r.t. gamma / lmbda tensors are not implemented")
+
+
 def generalized_advantage_estimate(
     gamma: float,
     lmbda: float,
@@ -374,9 +473,10 @@ def generalized_advantage_estimate(
     Returns ``(advantage, value_target)``.  All tensors must have shape
     ``[*Batch x TimeSteps x *F]``; ``terminated`` defaults to ``done``.
     """
-    if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
-        raise NotImplementedError(_GRAD_MSG.format("generalized_advantage_estimate"))
     call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
+    if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
+        _no_coef_grad("generalized_advantage_estimate", gamma, lmbda)
+        return _GaeFunction.apply(state_value, next_state_value, reward, call, None)
     adv, vt, _ = _launch_gae(call)
     return adv, vt
 
@@ -394,10 +494,11 @@ def vec_generalized_advantage_estimate(
 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Vectorized GAE (reference: functional.py:272-370).  Same kernels as the loop variant:
     the result is exact rather than filter-truncated."""
-    if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
-        raise NotImplementedError(_GRAD_MSG.format("vec_generalized_advantage_estimate"))
     call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
     call.out_dtype = state_value.dtype  # functional.py:314
+    if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
+        _no_coef_grad("vec_generalized_advantage_estimate", gamma, lmbda)
+        return _GaeFunction.apply(state_value, next_state_value, reward, call, None)
     adv, vt, _ = _launch_gae(call)
     return adv, vt
 
@@ -470,9 +571,12 @@ def gae_normalized(gamma, lmbda, state_value, next_state_value, reward, done, te
     ``distributed`` / ``group``: the batch is sharded over ranks along the env dimension; the
     fp64 moments are all-reduced (one 24-byte RCCL all-reduce) between the GAE kernel and the
     scale pass, so every rank normalises with the global statistics."""
-    if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
-        raise NotImplementedError(_GRAD_MSG.format("gae_normalized"))
     call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
+    if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
+        # differentiable path: GAE through the autograd function, normalisation as the reference's torch ops
+        _no_coef_grad("gae_normalized", gamma, lmbda)
+        adv, vt = _GaeFunction.apply(state_value, next_state_value, reward, call, None)
+        return (adv - adv.mean()) / adv.std().clamp_min(eps), vt
     dist = torch.distributed
     if (distributed or group is not None) and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         adv, vt, stats = _launch_gae(call, want_stats=True, algo=ALGO_AUTO if algo == ALGO_FUSED else algo)
@@ -649,9 +753,10 @@ def td_lambda_return_estimate(
     ``rolling_gamma=False`` (each return uses the gamma / lmbda of its own first step for the
     whole tail) runs the O(T^2) kernel and needs a gamma or lmbda tensor.
     """
-    if _needs_grad(next_state_value, reward, gamma, lmbda):
-        raise NotImplementedError(_GRAD_MSG.format("td_lambda_return_estimate"))
     call = _prepare_td_lambda(gamma, lmbda, next_state_value, reward, done, terminated, rolling_gamma, time_dim)
+    if _needs_grad(next_state_value, reward, gamma, lmbda):
+        _no_coef_grad("td_lambda_return_estimate", gamma, lmbda)
+        return _TdLambdaFunction.apply(next_state_value, reward, call, next_state_value.dtype)
     return _launch_td_lambda(call, next_state_value.dtype)
 
 
@@ -673,9 +778,6 @@ def vec_td_lambda_return_estimate(
         terminated = done
     if not (next_state_value.shape == reward.shape == done.shape == terminated.shape):
         raise RuntimeError(SHAPE_ERR)
-    if _needs_grad(next_state_value, reward, gamma, lmbda):
-        raise NotImplementedError(_GRAD_MSG.format("vec_td_lambda_return_estimate"))
-
     def _is_scalar(t):
         return not isinstance(t, torch.Tensor) or t.numel() == 1
 
@@ -700,6 +802,9 @@ def vec_td_lambda_return_estimate(
     if _is_scalar(gamma) and _is_scalar(lmbda):
         rolling_gamma = None  # the reference's fast path ignores it (functional.py:1101-1110)
     call = _prepare_td_lambda(gamma, lmbda, next_state_value, reward, done, terminated, rolling_gamma, time_dim, vec=True)
+    if _needs_grad(next_state_value, reward, gamma, lmbda):
+        _no_coef_grad("vec_td_lambda_return_estimate", gamma, lmbda)
+        return _TdLambdaFunction.apply(next_state_value, reward, call, next_state_value.dtype)
     return _launch_td_lambda(call, next_state_value.dtype)
 
 
