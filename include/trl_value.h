@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TRL_ABI_VERSION 1
+#define TRL_ABI_VERSION 2
 
 enum { TRL_F32 = 0, TRL_F64 = 1 };
 
@@ -68,7 +68,12 @@ const char *trl_last_kernel(void);
 /* Bytes of device workspace the calls below need for a problem of this size.  The workspace must be
  * 256-byte aligned and ZERO-FILLED ONCE before its first use (it carries the epoch of the fused
  * kernel's in-launch exchange); afterwards only this library writes it.  Calls that share a
- * workspace must not overlap in time (one workspace per stream). */
+ * workspace must not overlap in time (one workspace per stream).
+ * Besides the statistics, the workspace carries the chunk records of the decoupled look-back scan:
+ * when there are too few rows to fill the chip (O < #CUs / 2, I == 1, T of 8 chunks or more) and a
+ * workspace of this size is passed, trl_gae_fwd (stats == NULL), trl_td_lambda_fwd and
+ * trl_vtrace_fwd scan the chunks of a row in parallel; without a workspace they scan each row's
+ * chunks in turn inside one block (same results). */
 size_t trl_workspace_bytes(int64_t O, int64_t T, int64_t I);
 
 /*
@@ -124,6 +129,7 @@ int trl_gae_normalize_fwd(void *stream, int val_dtype, int coef_dtype,
  * gamma_t / lmbda_t: optional per-element tensors (coef_dtype), else scalars.
  * rolling_gamma == 0: the O(T^2) variant (functional.py:877-887): R_k is the tail run with
  *   gamma_k, lmbda_k held fixed; requires gamma_t or lmbda_t.
+ * workspace: optional (NULL, 0), see trl_workspace_bytes.
  */
 int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype,
                       const void *reward, const void *next_state_value,
@@ -131,7 +137,7 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype,
                       const void *gamma_t, const void *lmbda_t,
                       double gamma, double lmbda, int rolling_gamma,
                       int64_t O, int64_t T, int64_t I,
-                      void *returns, int algo);
+                      void *returns, void *workspace, size_t workspace_bytes, int algo);
 
 /*
  * V-trace advantage and targets.
@@ -141,6 +147,7 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype,
  *   vs = x + v;  vs+_t = vs_{t+1} (t < T-1), v'_{T-1} (t = T-1; the shift ignores done)
  *   advantage = rb*(r + gamma*(1-term)*vs+ - v)
  * Outputs have dtype promote(val_dtype, coef_dtype) (the reference allocates nothing in val_dtype).
+ * workspace: optional (NULL, 0), see trl_workspace_bytes.
  */
 int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype,
                    const void *log_pi, const void *log_mu,
@@ -148,7 +155,7 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype,
                    const uint8_t *done, const uint8_t *terminated,
                    const void *gamma_t, double gamma, double rho_thresh, double c_thresh,
                    int64_t O, int64_t T, int64_t I,
-                   void *advantage, void *vs, int algo);
+                   void *advantage, void *vs, void *workspace, size_t workspace_bytes, int algo);
 
 /*
  * Advantage normalisation from precomputed statistics.

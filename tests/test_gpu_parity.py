@@ -298,3 +298,60 @@ def test_fused_falls_back_when_not_eligible():
     torch.testing.assert_close(adv.cpu(), O.normalize(oadv, 1e-4), rtol=2e-5, atol=2e-5)
     with pytest.raises(RuntimeError, match="FUSED family needs"):
         F._launch_gae_normalize(F._prepare_gae(0.99, 0.95, cu(v), cu(nv), cu(r), cu(done), cu(term), -2), 1e-4, algo=F.ALGO_FUSED)
+
+
+# few, very long rows: one chunk per block with decoupled look-back between the chunks of a row
+LOOKBACK_SHAPES = [(1, 100000, 1), (4, 50000, 1), (3, 8193, 1), (2, 16384, 1), (100, 8192, 1), (1, 9000, 1)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", LOOKBACK_SHAPES, ids=[f"{s[0]}x{s[1]}" for s in LOOKBACK_SHAPES])
+def test_lookback_long_rows_vs_oracle(shape, dtype):
+    """Rows of 8 chunks or more with too few rows to fill the chip take the look-back kernel (all three
+    estimators, scalar and per-element gamma); same bar as the other SCAN kernels, and the result equals
+    the in-block chunk loop's (the path taken when no workspace is passed) to the same bar."""
+    r, v, nv, done, term, gam, lp, lm = _rand_inputs(shape, dtype, seed=5, p_term=0.001, p_trunc=0.001)
+    chunk = 256 * (4 if dtype == torch.float32 else 2)
+    eligible = shape[1] >= 8 * chunk - chunk + 1
+    for gamma in (0.99, gam):
+        oadv, ovt = O.gae(gamma, 0.95, v, nv, r, done, term)
+        oret = O.td_lambda(gamma, 0.95, nv, r, done, term)
+        ova, ovs = O.vtrace(gamma, lp, lm, v, nv, r, done, term)
+        gcall = F._prepare_gae(cu(gamma), 0.95, cu(v), cu(nv), cu(r), cu(done), cu(term), -2)
+        tcall = F._prepare_td_lambda(cu(gamma), 0.95, cu(nv), cu(r), cu(done), cu(term), None, -2)
+        vcall = F._prepare_vtrace(cu(gamma), cu(lp), cu(lm), cu(v), cu(nv), cu(r), cu(done), cu(term), 1.0, 1.0, -2)
+        for rep in range(2):  # the second call re-uses the (re-zeroed) records of the first
+            adv, vt, _ = F._launch_gae(gcall, algo=SCAN)
+            assert ("lookback" in F.last_kernel()) == eligible, F.last_kernel()
+            check(adv, oadv, False, done)
+            check(vt, ovt, False, done)
+            ret = F._launch_td_lambda(tcall, dtype, algo=SCAN)
+            assert ("lookback" in F.last_kernel()) == eligible, F.last_kernel()
+            check(ret, oret, False)
+            va, vs = F._launch_vtrace(vcall, algo=SCAN)
+            assert ("lookback" in F.last_kernel()) == eligible, F.last_kernel()
+            check(va, ova, False)
+            check(vs, ovs, False)
+        # stats requested -> the in-block chunk loop (partials per block), same values
+        adv2, vt2, st = F._launch_gae(gcall, want_stats=True, algo=SCAN)
+        assert "long" in F.last_kernel()
+        check(adv2, oadv, False, done)
+
+
+def test_lookback_undiscounted_carry_crosses_every_chunk():
+    """gamma = lmbda = 1 and no done: the carry out of the last chunk reaches step 0 through every
+    aggregate, so a wrong composition order or a stale record would show at full magnitude."""
+    shape = (2, 40000, 1)
+    g = torch.Generator().manual_seed(9)
+    r = torch.randn(shape, generator=g, dtype=torch.float64)
+    v = torch.randn(shape, generator=g, dtype=torch.float64)
+    nv = torch.randn(shape, generator=g, dtype=torch.float64)
+    done = torch.zeros(shape, dtype=torch.bool)
+    oadv, ovt = O.gae(1.0, 1.0, v, nv, r, done, done)
+    gcall = F._prepare_gae(1.0, 1.0, cu(v), cu(nv), cu(r), cu(done), cu(done), -2)
+    adv, vt, _ = F._launch_gae(gcall, algo=SCAN)
+    assert "lookback" in F.last_kernel()
+    torch.testing.assert_close(adv.cpu(), oadv, rtol=1e-11, atol=1e-9)
+    oret = O.td_lambda(1.0, 1.0, nv, r, done, done)
+    tcall = F._prepare_td_lambda(1.0, 1.0, cu(nv), cu(r), cu(done), cu(done), None, -2)
+    torch.testing.assert_close(F._launch_td_lambda(tcall, torch.float64, algo=SCAN).cpu(), oret, rtol=1e-11, atol=1e-9)

@@ -18,7 +18,7 @@ import warnings
 
 _LIB_NAME = "libtrl_value.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXTENSION_WARNING = (
     f"Failed to load the torchrl_amd HIP library ({_LIB_PATH}). The value estimators "
@@ -48,9 +48,9 @@ _PROTOTYPES = {
     "trl_gae_normalize_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl,
                                      _i64, _i64, _i64, _vp, _vp, _dbl, _vp, _vp, _sz, _int]),
     "trl_td_lambda_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int,
-                                 _i64, _i64, _i64, _vp, _int]),
+                                 _i64, _i64, _i64, _vp, _vp, _sz, _int]),
     "trl_vtrace_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl,
-                              _i64, _i64, _i64, _vp, _vp, _int]),
+                              _i64, _i64, _i64, _vp, _vp, _vp, _sz, _int]),
     "trl_normalize": (_int, [_vp, _int, _vp, _i64, _vp, _dbl, _vp]),
     "trl_moments": (_int, [_vp, _int, _vp, _i64, _vp, _vp, _sz]),
 }

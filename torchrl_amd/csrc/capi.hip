@@ -47,6 +47,22 @@ i64 max_partials(i64 O, i64 T, i64 I) {
     return m > c ? m : c;
 }
 
+// the look-back records follow the partials, on a 256-byte boundary
+size_t lookback_offset(i64 O, i64 T, i64 I) {
+    const size_t end = kWsPartialsOffset + (size_t)max_partials(O, T, I) * 2 * sizeof(double);
+    return (end + 255) & ~(size_t)255;
+}
+
+// look-back region of a caller workspace (nullptr when the workspace is absent, misaligned or too small)
+void *lb_region(void *workspace, size_t workspace_bytes, i64 O, i64 T, i64 I, size_t *bytes) {
+    const size_t off = lookback_offset(O, T, I);
+    if (!workspace || workspace_bytes <= off || ((uintptr_t)workspace & 255)) { *bytes = 0; return nullptr; }
+    *bytes = workspace_bytes - off;
+    return (char *)workspace + off;
+}
+
+
+
 }  // namespace
 
 extern "C" {
@@ -57,7 +73,7 @@ const char *trl_last_kernel(void) { return g_kernel; }
 
 size_t trl_workspace_bytes(int64_t O, int64_t T, int64_t I) {
     if (O <= 0 || T <= 0 || I <= 0) return 0;
-    return kWsPartialsOffset + (size_t)max_partials(O, T, I) * 2 * sizeof(double) + 256;
+    return lookback_offset(O, T, I) + scan_lookback_bytes(O, T, I) + 256;
 }
 
 int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
@@ -82,7 +98,9 @@ int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward,
     if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ)
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: unknown algo %d", algo);
     LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
-    if (algo != TRL_ALGO_SEQ) res = launch_gae_scan(s, val_dtype, coef_dtype, a);
+    size_t lb_bytes = 0;
+    void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
+    if (algo != TRL_ALGO_SEQ) res = launch_gae_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
         return fail(TRL_ERR_UNSUPPORTED, "trl_gae_fwd: SCAN family does not support this shape (needs I == 1)");
     if (res.status == TRL_ERR_UNSUPPORTED) res = launch_gae_seq(s, val_dtype, coef_dtype, a);
@@ -100,7 +118,7 @@ int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward,
 int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *next_state_value,
                       const uint8_t *done, const uint8_t *terminated, const void *gamma_t, const void *lmbda_t,
                       double gamma, double lmbda, int rolling_gamma, int64_t O, int64_t T, int64_t I,
-                      void *returns, int algo) {
+                      void *returns, void *workspace, size_t workspace_bytes, int algo) {
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td_lambda_fwd: bad dtype");
     if (int rc = check_dims("trl_td_lambda_fwd", O, T, I)) return rc;
     if (!reward || !next_state_value || !done || !terminated || !returns)
@@ -112,7 +130,9 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype, const void *r
     LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
     if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ)
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td_lambda_fwd: unknown algo %d", algo);
-    if (rolling_gamma && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN)) res = launch_td_lambda_scan(s, val_dtype, coef_dtype, a);
+    size_t lb_bytes = 0;
+    void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
+    if (rolling_gamma && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN)) res = launch_td_lambda_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
         return fail(TRL_ERR_UNSUPPORTED, "trl_td_lambda_fwd: SCAN family does not support this case (needs I == 1, rolling gamma)");
     if (res.status == TRL_ERR_UNSUPPORTED) res = launch_td_lambda_seq(s, val_dtype, coef_dtype, a, rolling_gamma);
@@ -126,7 +146,7 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_
                    const void *state_value, const void *next_state_value, const void *reward,
                    const uint8_t *done, const uint8_t *terminated, const void *gamma_t, double gamma,
                    double rho_thresh, double c_thresh, int64_t O, int64_t T, int64_t I,
-                   void *advantage, void *vs, int algo) {
+                   void *advantage, void *vs, void *workspace, size_t workspace_bytes, int algo) {
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_fwd: bad dtype");
     if (int rc = check_dims("trl_vtrace_fwd", O, T, I)) return rc;
     if (!log_pi || !log_mu || !state_value || !next_state_value || !reward || !done || !terminated || !advantage || !vs)
@@ -137,7 +157,9 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_
     LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
     if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ)
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_fwd: unknown algo %d", algo);
-    if (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN) res = launch_vtrace_scan(s, val_dtype, coef_dtype, a);
+    size_t lb_bytes = 0;
+    void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
+    if (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN) res = launch_vtrace_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
         return fail(TRL_ERR_UNSUPPORTED, "trl_vtrace_fwd: SCAN family does not support this shape (needs I == 1)");
     if (res.status == TRL_ERR_UNSUPPORTED) res = launch_vtrace_seq(s, val_dtype, coef_dtype, a);

@@ -120,9 +120,11 @@ LaunchResult launch_gae_seq(hipStream_t s, int vdt, int cdt, const GaeArgs &a);
 LaunchResult launch_td_lambda_seq(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, int rolling);
 LaunchResult launch_vtrace_seq(hipStream_t s, int vdt, int cdt, const VtraceArgs &a);
 
-LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a);
-LaunchResult launch_td_lambda_scan(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a);
-LaunchResult launch_vtrace_scan(hipStream_t s, int vdt, int cdt, const VtraceArgs &a);
+// lb_ws / lb_bytes: optional look-back region of the workspace (scan_lookback_bytes), else nullptr / 0
+LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a, void *lb_ws, size_t lb_bytes);
+LaunchResult launch_td_lambda_scan(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, void *lb_ws, size_t lb_bytes);
+LaunchResult launch_vtrace_scan(hipStream_t s, int vdt, int cdt, const VtraceArgs &a, void *lb_ws, size_t lb_bytes);
+size_t scan_lookback_bytes(i64 O, i64 T, i64 I);
 i64 scan_max_partials(i64 O, i64 T, i64 I);
 i64 seq_max_partials(i64 O, i64 T, i64 I);
 

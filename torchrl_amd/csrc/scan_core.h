@@ -351,9 +351,12 @@ struct LaneGeom {
 //   chunk; on exit those of the chunk's first element.  Ignored when WAVE_INDEP.
 //   scan_lanes: upper bound on the number of consecutive lanes one row spans (64 = no bound).
 //   emit(xs, row_end, x_in, v_next): consumes the per-step results.
-template <class Op, bool WAVE_INDEP, class Emit>
+//   carry_fn(sh, buf, Xc, Xv): called by every thread once the wave aggregates are in LDS; a kernel
+//   that learns its carry from other blocks (decoupled look-back) resolves Xc / Xv there.
+template <class Op, bool WAVE_INDEP, class Emit, class CarryFn>
 __device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int buf, int nvalid, unsigned t0, unsigned T,
-                                           int scan_lanes, typename Op::TC &Xc, typename Op::TS &Xv, Emit &&emit) {
+                                           int scan_lanes, typename Op::TC &Xc, typename Op::TS &Xv, Emit &&emit,
+                                           CarryFn &&carry_fn) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
     constexpr int V = Op::V;
@@ -433,6 +436,7 @@ __device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int
             if (Op::kNeedsNext) sh.v0[buf][w] = op.first_value();
         }
         __syncthreads();
+        carry_fn(sh, buf, Xc, Xv);
         TC x = Xc;
         TS xv = Xv;
         Cw = x;
@@ -460,6 +464,13 @@ __device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int
         if (e < nvalid) xp = xs[e];
     }
     emit(xs, row_end, x_in, v_next);
+}
+
+template <class Op, bool WAVE_INDEP, class Emit>
+__device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int buf, int nvalid, unsigned t0, unsigned T,
+                                           int scan_lanes, typename Op::TC &Xc, typename Op::TS &Xv, Emit &&emit) {
+    scan_chunk<Op, WAVE_INDEP>(op, sh, buf, nvalid, t0, T, scan_lanes, Xc, Xv, emit,
+                               [](TeamShared<Op> &, int, typename Op::TC &, typename Op::TS &) {});
 }
 
 // lanes one row can span inside a wave (bounds the shuffle steps); 64 when unknown

@@ -297,10 +297,149 @@ __global__ __launch_bounds__(kLongThreads) void scan_long_kernel(typename Op::Ar
     }
 }
 
+
+// ---- LONG rows, few of them: one chunk per block, decoupled look-back between chunks ----------------
+// When there are too few rows to fill the chip (O < ~2 * #CUs) a row's chunks are scanned in PARALLEL:
+// every block takes one chunk, publishes the chunk's aggregate map, then resolves its carry by
+// walking the records of the chunks that follow it in time ("look-back", here toward later time
+// because the scan runs from T-1 to 0) until it meets one whose inclusive value is known, and
+// publishes its own inclusive value.  Chunks are handed out through an atomic ticket in reverse
+// time order, so every chunk a block may wait on belongs to a block that has already started and
+// publishes its aggregate without waiting on anyone: progress is guaranteed for any dispatch order
+// or XCD placement.  Records are {flag | payload}: the payload is written with agent-scope
+// (write-through) stores, drained (s_waitcnt vmcnt(0)), then the flag is stored; the consumer polls
+// the flag with agent-scope loads and reads the payload with agent-scope loads
+// (MI355X_MICROARCH.md, valid hand-off forms).  Ticket and records are zeroed by a memset node on the
+// same stream before every launch.  Spins are bounded (1 s): on timeout NaNs are written.
+struct LbRecord {             // one 64-byte line per chunk; a field is never rewritten once its flag is up
+    unsigned long long flag;  // 0 none, 1 aggregate {a, b} valid, 2 inclusive {x} valid too
+    unsigned long long a, b;  // aggregate map of the chunk (double bits)
+    unsigned long long x;     // inclusive value: x of the chunk's first step
+    unsigned long long v0;    // V-trace: state_value of the chunk's first step
+    unsigned long long pad[3];
+};
+static_assert(sizeof(LbRecord) == 64, "record size");
+struct LbHeader {
+    unsigned ticket;
+    unsigned error;
+    unsigned pad[62];
+};
+
+template <typename T>
+__device__ __forceinline__ unsigned long long lb_bits(T x) { return (unsigned long long)__double_as_longlong((double)x); }
+template <typename T>
+__device__ __forceinline__ T lb_val(unsigned long long b) { return (T)__longlong_as_double((long long)b); }
+__device__ __forceinline__ void lb_store(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long lb_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <class Op, bool VEC>
+__global__ __launch_bounds__(kLongThreads) void scan_lookback_kernel(typename Op::Args args, ScanGeom geo, LbHeader *hdr,
+                                                                    LbRecord *rec) {
+    typedef typename Op::TC TC;
+    typedef typename Op::TS TS;
+    constexpr int V = Op::V;
+    constexpr int kChunk = kLongThreads * V;
+    __shared__ TeamShared<Op> sh;
+    __shared__ unsigned s_ticket;
+    __shared__ TC s_xc;
+    __shared__ TS s_xv;
+    const unsigned T = (unsigned)geo.T;
+    const int lane_off = (int)threadIdx.x * V;
+    const int nchunks = (int)((geo.T + kChunk - 1) / kChunk);
+
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&hdr->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const i64 k = s_ticket;
+    const i64 row = k / nchunks;
+    const int c = nchunks - 1 - (int)(k % nchunks);  // later chunks of a row draw earlier tickets
+    if (row >= geo.O) return;
+    i64 cnt = geo.T - (i64)c * kChunk;
+    if (cnt > kChunk) cnt = kChunk;
+    const i64 start = row * geo.T + (i64)c * kChunk;
+    const int nvalid = clamp_nvalid((int)cnt, lane_off, V);
+    const i64 flat = start + lane_off;
+    LbRecord *myrec = rec + row * nchunks + c;
+
+    typename Op::Raw raw;
+    load_inputs<Op, VEC>(args, flat, nvalid, raw);
+    Op op;
+    op.prepare(args, raw);
+    TC Xc = (TC)0;
+    TS Xv = (TS)0;
+    double s = 0.0, ss = 0.0;
+    scan_chunk<Op, false>(
+        op, sh, 0, nvalid, (unsigned)((i64)c * kChunk + lane_off), T, kWave, Xc, Xv,
+        [&](const TC(&xs)[V], const bool(&row_end)[V], TC x_in, TS v_next) {
+            typename Op::TO o0[V], o1[V];
+            op.outputs(nvalid, xs, row_end, x_in, v_next, o0, o1, s, ss);
+            store_outputs<Op, VEC>(args, flat, nvalid, o0, o1);
+        },
+        [&](TeamShared<Op> &shm, int buf, TC &xc, TS &xv) {
+            if (threadIdx.x == 0) {
+                // this chunk's aggregate: x_first = G0(G1(G2(G3(x_in))))
+                Aff<TC> agg{shm.a[buf][kWaves - 1], shm.b[buf][kWaves - 1], shm.h[buf][kWaves - 1]};
+#pragma unroll
+                for (int w = kWaves - 2; w >= 0; --w) agg = compose(Aff<TC>{shm.a[buf][w], shm.b[buf][w], shm.h[buf][w]}, agg);
+                const TS my_v0 = Op::kNeedsNext ? shm.v0[buf][0] : (TS)0;
+                TC carry = (TC)0;
+                TS carry_v = (TS)0;
+                bool ok = true;
+                if (agg.h) {
+                    // the chunk holds its row's end: inclusive value known at once
+                    lb_store(&myrec->x, lb_bits(agg.b));
+                    lb_store(&myrec->v0, lb_bits(my_v0));
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    lb_store(&myrec->flag, 2ull);
+                } else {
+                    lb_store(&myrec->a, lb_bits(agg.a));
+                    lb_store(&myrec->b, lb_bits(agg.b));
+                    lb_store(&myrec->v0, lb_bits(my_v0));
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    lb_store(&myrec->flag, 1ull);
+                    // look back: compose the aggregates of the following chunks until an inclusive value
+                    Aff<TC> acc{(TC)1, (TC)0, 0};
+                    const unsigned long long t_start = wall_clock64();
+                    for (int cur = c + 1;; ++cur) {
+                        const LbRecord *r = rec + row * nchunks + cur;
+                        unsigned long long f;
+                        while ((f = lb_load(&r->flag)) == 0ull) {
+                            if (wall_clock64() - t_start > 100000000ull) { ok = false; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        if (!ok) break;
+                        if (cur == c + 1) carry_v = lb_val<TS>(lb_load(&r->v0));
+                        if (f == 2ull) {
+                            carry = apply(acc, lb_val<TC>(lb_load(&r->x)));
+                            break;
+                        }
+                        const TC ra = lb_val<TC>(lb_load(&r->a)), rb = lb_val<TC>(lb_load(&r->b));
+                        acc = compose(acc, Aff<TC>{ra, rb, 0});
+                    }
+                    if (!ok) {
+                        hdr->error = 1u;
+                        carry = (TC)__longlong_as_double(0x7ff8000000000000LL);
+                    }
+                    lb_store(&myrec->x, lb_bits(apply(agg, carry)));
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    lb_store(&myrec->flag, 2ull);
+                }
+                s_xc = carry;
+                s_xv = carry_v;
+            }
+            __syncthreads();
+            xc = s_xc;
+            xv = s_xv;
+        });
+}
+
 // ---- host side ----------------------------------------------------------------------------------
 struct Plan {
     bool ok;
-    bool long_rows, wave_indep, vec, interleaved;
+    bool long_rows, wave_indep, vec, interleaved, lookback;
     int rows_per_chunk;
     i64 nchunks;
     i64 nblocks;
@@ -324,7 +463,7 @@ int device_cus() {
 }
 
 // V: elements per lane; ptr_align_ok: every tensor base pointer is 16-byte aligned.
-Plan make_plan(i64 O, i64 T, i64 I, int V, bool ptr_align_ok, int cus) {
+Plan make_plan(i64 O, i64 T, i64 I, int V, bool ptr_align_ok, int cus, size_t lb_bytes = 0, bool want_partials = false) {
     Plan p{};
     const i64 chunk = (i64)kTeam * V;
     if (I > 1) {
@@ -368,13 +507,22 @@ Plan make_plan(i64 O, i64 T, i64 I, int V, bool ptr_align_ok, int cus) {
         p.nblocks = O < kMaxLongGrid ? O : kMaxLongGrid;
         p.vec = ptr_align_ok && (T % V == 0);
         p.wave_indep = false;
+        // too few rows to fill the chip (measured crossover: ~#CUs/2 rows; the in-block chunk loop streams
+        // ~13 GB/s per row): scan each row's chunks in parallel with decoupled look-back
+        const i64 nch = (T + chunk - 1) / chunk;
+        if (!want_partials && 2 * O < (i64)cus && nch >= 8 && O * nch <= (1LL << 22) &&
+            lb_bytes >= sizeof(LbHeader) + (size_t)(O * nch) * sizeof(LbRecord)) {
+            p.lookback = true;
+            p.nchunks = nch;
+            p.nblocks = O * nch;
+        }
     }
     return p;
 }
 
 template <class Op>
 LaunchResult launch_scan(hipStream_t s, const typename Op::Args &a, const Plan &p, i64 O, i64 T, i64 I, double *partials,
-                         const char *name) {
+                         const char *name, void *lb_ws = nullptr) {
     ScanGeom geo{O, T, p.rows_per_chunk, scan_lanes_for(T, Op::V, p.wave_indep), p.nchunks};
     const dim3 grid((unsigned)p.nblocks);
     if (p.interleaved) {
@@ -382,6 +530,13 @@ LaunchResult launch_scan(hipStream_t s, const typename Op::Args &a, const Plan &
         if (p.wave_indep) { if (p.vec) TRL_LAUNCH(true, true); else TRL_LAUNCH(false, true); }
         else              { if (p.vec) TRL_LAUNCH(true, false); else TRL_LAUNCH(false, false); }
 #undef TRL_LAUNCH
+    } else if (p.lookback) {
+        LbHeader *hdr = (LbHeader *)lb_ws;
+        LbRecord *rec = (LbRecord *)((char *)lb_ws + sizeof(LbHeader));
+        if (hipMemsetAsync(lb_ws, 0, sizeof(LbHeader) + (size_t)p.nblocks * sizeof(LbRecord), s) != hipSuccess)
+            return LaunchResult{4, 0, nullptr};
+        if (p.vec) hipLaunchKernelGGL((scan_lookback_kernel<Op, true>), grid, dim3(kLongThreads), 0, s, a, geo, hdr, rec);
+        else hipLaunchKernelGGL((scan_lookback_kernel<Op, false>), grid, dim3(kLongThreads), 0, s, a, geo, hdr, rec);
     } else if (p.long_rows) {
         if (p.vec) hipLaunchKernelGGL((scan_long_kernel<Op, true>), grid, dim3(kLongThreads), 0, s, a, geo, partials);
         else hipLaunchKernelGGL((scan_long_kernel<Op, false>), grid, dim3(kLongThreads), 0, s, a, geo, partials);
@@ -408,45 +563,53 @@ LaunchResult dispatch_scan(int vdt, int cdt, F &&f) {
 
 }  // namespace
 
+size_t scan_lookback_bytes(i64 O, i64 T, i64 I) {
+    // worst case over dtypes: chunk = 512 steps (fp64)
+    if (I != 1 || T <= 512) return 0;
+    const i64 nch = (T + 511) / 512;
+    if (O >= 4096 || O * nch > (1LL << 22)) return 0;
+    return sizeof(LbHeader) + (size_t)(O * nch) * sizeof(LbRecord);
+}
+
 i64 scan_max_partials(i64 O, i64 T, i64 I) {
     (void)O; (void)T; (void)I;
     return 4096;  // >= every grid this file launches (LONG <= 2048, SHORT <= 512, interleaved <= 4 * #CUs)
 }
 
-LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a) {
+LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a, void *lb_ws, size_t lb_bytes) {
     const bool al = aligned16(a.reward) && aligned16(a.value) && aligned16(a.next_value) && aligned16(a.done) &&
                     aligned16(a.terminated) && aligned16(a.gamma_t) && aligned16(a.lg_t) && aligned16(a.advantage) &&
                     aligned16(a.value_target);
     return dispatch_scan<GaeOp, GaeArgs>(vdt, cdt, [&](auto op) {
         typedef decltype(op) Op;
-        Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus());
+        Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus(), lb_ws ? lb_bytes : 0, a.partials != nullptr);
         if (!p.ok) return LaunchResult{2, 0, nullptr};
         return launch_scan<Op>(s, a, p, a.O, a.T, a.I, a.partials,
-                               p.interleaved ? "gae_scan_interleaved" : p.long_rows ? "gae_scan_long" : "gae_scan_short");
+                               p.interleaved ? "gae_scan_interleaved" : p.lookback ? "gae_scan_lookback" : p.long_rows ? "gae_scan_long" : "gae_scan_short", lb_ws);
     });
 }
 
-LaunchResult launch_td_lambda_scan(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a) {
+LaunchResult launch_td_lambda_scan(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, void *lb_ws, size_t lb_bytes) {
     const bool al = aligned16(a.reward) && aligned16(a.next_value) && aligned16(a.done) && aligned16(a.terminated) &&
                     aligned16(a.gamma_t) && aligned16(a.lmbda_t) && aligned16(a.returns);
     return dispatch_scan<TdLambdaOp, TdLambdaArgs>(vdt, cdt, [&](auto op) {
         typedef decltype(op) Op;
-        Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus());
+        Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus(), lb_ws ? lb_bytes : 0, false);
         if (!p.ok) return LaunchResult{2, 0, nullptr};
         return launch_scan<Op>(s, a, p, a.O, a.T, a.I, nullptr,
-                               p.interleaved ? "td_lambda_scan_interleaved" : p.long_rows ? "td_lambda_scan_long" : "td_lambda_scan_short");
+                               p.interleaved ? "td_lambda_scan_interleaved" : p.lookback ? "td_lambda_scan_lookback" : p.long_rows ? "td_lambda_scan_long" : "td_lambda_scan_short", lb_ws);
     });
 }
 
-LaunchResult launch_vtrace_scan(hipStream_t s, int vdt, int cdt, const VtraceArgs &a) {
+LaunchResult launch_vtrace_scan(hipStream_t s, int vdt, int cdt, const VtraceArgs &a, void *lb_ws, size_t lb_bytes) {
     const bool al = aligned16(a.log_pi) && aligned16(a.log_mu) && aligned16(a.value) && aligned16(a.next_value) &&
                     aligned16(a.reward) && aligned16(a.done) && aligned16(a.terminated) && aligned16(a.gamma_t) &&
                     aligned16(a.advantage) && aligned16(a.vs);
     return dispatch_scan<VtraceOp, VtraceArgs>(vdt, cdt, [&](auto op) {
         typedef decltype(op) Op;
-        Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus());
+        Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus(), lb_ws ? lb_bytes : 0, false);
         if (!p.ok) return LaunchResult{2, 0, nullptr};
         return launch_scan<Op>(s, a, p, a.O, a.T, a.I, nullptr,
-                               p.interleaved ? "vtrace_scan_interleaved" : p.long_rows ? "vtrace_scan_long" : "vtrace_scan_short");
+                               p.interleaved ? "vtrace_scan_interleaved" : p.lookback ? "vtrace_scan_lookback" : p.long_rows ? "vtrace_scan_long" : "vtrace_scan_short", lb_ws);
     });
 }

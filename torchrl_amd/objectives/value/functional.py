@@ -317,6 +317,14 @@ def _workspace(lib, dev, O, T, I):
     return ws
 
 
+def _lookback_workspace(lib, dev, O, T, I):
+    """Workspace for the decoupled look-back scan of few, very long rows (trl_value.h:
+    trl_workspace_bytes); None for every other shape (the library then needs none)."""
+    if I != 1 or T < 2048 or O >= 4096:
+        return None
+    return _workspace(lib, dev, O, T, I)
+
+
 def _launch_gae(c: _GaeCall, want_stats: bool = False, algo: int = ALGO_AUTO, out=None):
     lib = _extension.get_lib()
     _require_hip(c.next_value)
@@ -326,8 +334,10 @@ def _launch_gae(c: _GaeCall, want_stats: bool = False, algo: int = ALGO_AUTO, ou
     ws_bytes = 0
     if want_stats:
         ws = _workspace(lib, dev, c.O, c.T, c.I)
-        ws_bytes = ws.numel()
         stats = torch.empty(3, dtype=torch.float64, device=dev)
+    else:
+        ws = _lookback_workspace(lib, dev, c.O, c.T, c.I)
+    ws_bytes = ws.numel() if ws is not None else 0
     with torch.cuda.device(dev):
         rc = lib.trl_gae_fwd(
             _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.value), _ptr(c.next_value),
@@ -728,10 +738,12 @@ def _launch_td_lambda(c: _TdLambdaCall, out_dtype, algo: int = ALGO_AUTO) -> tor
     _require_hip(c.next_value)
     dev = c.next_value.device
     out = torch.empty(c.shape, dtype=c.vdt, device=dev)
+    ws = _lookback_workspace(lib, dev, c.O, c.T, c.I) if c.rolling else None
     with torch.cuda.device(dev):
         rc = lib.trl_td_lambda_fwd(
             _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.next_value), _ptr(c.done), _ptr(c.terminated),
-            _ptr(c.gamma_t), _ptr(c.lmbda_t), c.gamma, c.lmbda, 1 if c.rolling else 0, c.O, c.T, c.I, _ptr(out), algo)
+            _ptr(c.gamma_t), _ptr(c.lmbda_t), c.gamma, c.lmbda, 1 if c.rolling else 0, c.O, c.T, c.I, _ptr(out),
+            _ptr(ws), ws.numel() if ws is not None else 0, algo)
     _extension.check(rc, lib)
     return out if out_dtype == c.vdt else out.to(out_dtype)
 
@@ -924,11 +936,12 @@ def _launch_vtrace(c: _VtraceCall, algo: int = ALGO_AUTO):
     odt = torch.promote_types(c.vdt, c.cdt)
     adv = torch.empty(c.shape, dtype=odt, device=dev)
     vs = torch.empty(c.shape, dtype=odt, device=dev)
+    ws = _lookback_workspace(lib, dev, c.O, c.T, c.I)
     with torch.cuda.device(dev):
         rc = lib.trl_vtrace_fwd(
             _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.log_pi), _ptr(c.log_mu), _ptr(c.value), _ptr(c.next_value),
             _ptr(c.reward), _ptr(c.done), _ptr(c.terminated), _ptr(c.gamma_t), c.gamma, c.rho_thresh, c.c_thresh,
-            c.O, c.T, c.I, _ptr(adv), _ptr(vs), algo)
+            c.O, c.T, c.I, _ptr(adv), _ptr(vs), _ptr(ws), ws.numel() if ws is not None else 0, algo)
     _extension.check(rc, lib)
     return adv, vs
 
