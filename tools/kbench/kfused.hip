@@ -35,35 +35,12 @@ int main() {
     GaeArgs a{r, v, nv, d, t, nullptr, nullptr, 0.99f, 0.95f, 0.99f * 0.95f, 65536, 32, 1, o1, o2, nullptr};
     const int G = 256;
     FusedGeom geo{65536, 32, 32, 8, 65536 / 32, (double)N, 1e-4, 2};
-    run<0, 2>("full", a, geo, ws, G, 300);
-    run<0, 4, 2>("full", a, geo, ws, G, 300);
-    run<0, 2, 2>("full", a, geo, ws, 512, 300);
-    run<0, 4, 1>("full", a, geo, ws, 512, 300);
-    run<5, 4, 2>("plain scan", a, geo, ws, G, 300);
-    run<5, 2, 2>("plain scan", a, geo, ws, 512, 300);
-    run<1, 2>("no gather", a, geo, ws, G, 300);
-    run<2, 2>("no gather, no block reduce", a, geo, ws, G, 300);
-    run<3, 2>("no gather/reduce/scan steps", a, geo, ws, G, 300);
-    run<4, 2>("full, vt not deferred", a, geo, ws, G, 300);
-    double* part; CK(hipMalloc(&part, 16 * 1024));
-    run<5, 2>("plain scan (adv+vt stored at once)", a, geo, ws, G, 300);
-    run<6, 2>("plain scan + block partials", a, geo, ws, G, 300, part);
-    run<0, 2>("full (again)", a, geo, ws, G, 300);
-    {   // two-launch alternative: persistent scan + partials, then scale pass reducing the partials itself
-        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        for (int nbh : {256, 512, 1024, 2048}) {
-            auto f = [&] {
-                hipLaunchKernelGGL((gae_fused_kernel<Op, true, true, 2, 6>), dim3(G), dim3(kFusedThreads), 0, 0, a, geo, ws, part);
-                launch_normalize_from_partials(0, 0, o1, N, part, G, (double)N, 1e-4, o1, nullptr, nbh);
-            };
-            for (int i = 0; i < 20; ++i) f();
-            CK(hipDeviceSynchronize());
-            CK(hipEventRecord(e0));
-            for (int i = 0; i < 300; ++i) f();
-            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            printf("two launches: scan+partials, normalise(grid<=%d)   %8.2f us/step\n", nbh, ms * 1e3 / 300);
-        }
+    geo.slot_stride = 16;
+    for (int rep = 0; rep < 2; ++rep) {
+        run<4, 2>("full, vt not deferred", a, geo, ws, G, 300);
+        run<10, 2>("same, all loads up front", a, geo, ws, G, 300);
+        run<4, 4, 2>("full, vt not deferred", a, geo, ws, G, 300);
+        run<10, 4, 2>("same, all loads up front", a, geo, ws, G, 300);
     }
     for (int stride : {16}) {
       geo.slot_stride = stride;

@@ -9,7 +9,9 @@
 //   * one persistent block of 1024 threads per CU (grid = #CUs, all co-resident); a block is
 //     4 teams of 4 waves, each team scans K chunks of 256*V time steps exactly like the SCAN
 //     family (scan_core.h), with the next chunk's loads issued before the current one is scanned;
-//   * value_target is stored as soon as a chunk is done; the advantages stay in registers;
+//   * value_target is stored as soon as a chunk is done (stores issued before the publish cost
+//     nothing; anything issued between publish and gather delays the polls); the advantages stay
+//     in registers;
 //   * each block publishes its fp64 {sum, sumsq} as two 8-byte granules {value | 8-bit epoch tag}
 //     with write-through (agent-scope) stores; wave 0 of every block sweeps all blocks' granules
 //     with agent-scope loads until every tag matches (no fences, no atomics, no counters), sums
@@ -59,8 +61,9 @@ __device__ __forceinline__ unsigned long long tag_bits(double x, unsigned tag) {
 __device__ __forceinline__ double untag(unsigned long long b) { return __longlong_as_double((long long)(b & ~0xffull)); }
 
 // ABL (development only, tools/kbench): 0 = product; 1 = skip the gather (own block's moments);
-// 2 = also skip the block reduction; 3 = also skip the wave scan steps; 4 = product without the
-// deferred store of the last chunk's value_target.
+// 2 = also skip the block reduction; 3 = also skip the wave scan steps; 4 = last chunk's
+// value_target stored after the gather; 8 / 9 = value_target stored between publish and gather
+// (both slower than storing it at once); 10 = every chunk's loads issued up front.
 template <class Op, bool VEC, bool WAVE_INDEP, int K, int ABL = 0, int TEAMS = kTeams>
 __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::Args args, FusedGeom geo, FusedWs *ws,
                                                                   double *stats_out) {
@@ -68,7 +71,8 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
     typedef typename Op::TS TS;
     constexpr int V = Op::V;
     constexpr int NW = TEAMS * kTeam / kWave;
-    constexpr bool kDeferVt = ABL != 4;
+    constexpr bool kDeferVt = ABL == 4;  // measured slower (9.6 vs 9.2 us): stores issued before the publish are free
+    constexpr bool kVtWindow = ABL == 8 || ABL == 9;  // all value_target stores between publish and gather
     __shared__ TeamShared<Op> sh[TEAMS];
     __shared__ double red[2 * NW];
     __shared__ double bc[3];
@@ -84,6 +88,7 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
 
     TS adv_keep[K][V];
     TS vt_last[V];
+    TS vt_keep[kVtWindow ? K : 1][V];
     i64 flat_k[K];
     int nvalid_k[K];
 
@@ -103,18 +108,21 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
     };
 
     double s = 0.0, ss = 0.0;
-    typename Op::Raw raw[2];
-    {
+    constexpr bool kAllLoads = ABL == 10;  // every chunk's loads issued up front
+    constexpr int kRaw = kAllLoads ? K : 2;
+    typename Op::Raw raw[kRaw];
+#pragma unroll
+    for (int k = 0; k < (kAllLoads ? K : 1); ++k) {
         i64 start;
         int count;
-        geom_of(0, start, count);
-        load_inputs<Op, VEC>(args, start + lane_off, nvalid_of(count), raw[0]);
+        geom_of(k, start, count);
+        load_inputs<Op, VEC>(args, start + lane_off, nvalid_of(count), raw[k]);
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         i64 start;
         int count;
-        if (k + 1 < K) {
+        if (!kAllLoads && k + 1 < K) {
             geom_of(k + 1, start, count);
             load_inputs<Op, VEC>(args, start + lane_off, nvalid_of(count), raw[(k + 1) & 1]);
         }
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
         flat_k[k] = flat;
         nvalid_k[k] = nvalid;
         Op op;
-        op.prepare(args, raw[k & 1]);
+        op.prepare(args, raw[kAllLoads ? k : (k & 1)]);
         TC Xc = (TC)0;
         TS Xv = (TS)0;
         scan_chunk<Op, WAVE_INDEP>(op, sh[team], k & 1, nvalid, (unsigned)lane_off % T, T, (ABL == 3) ? 1 : geo.scan_lanes, Xc, Xv,
@@ -134,6 +142,8 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
                                            op.finish(nvalid, xs, adv_keep[k], vt, s, ss);
                                            store_n<VEC>((TS *)args.value_target, flat, nvalid, vt);
                                            store_n<VEC>((TS *)args.advantage, flat, nvalid, adv_keep[k]);
+                                       } else if constexpr (kVtWindow) {
+                                           op.finish(nvalid, xs, adv_keep[k], vt_keep[k], s, ss);
                                        } else if (kDeferVt && k == K - 1) {
                                            // the last chunk's value_target is stored after the gather: the
                                            // memory pipes are quiet while the moments are exchanged
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
         return;
     }
     // ---- block moments -> publish -> gather everybody's --------------------------------------------
-    if constexpr (ABL == 0 || ABL == 1 || ABL == 4 || ABL == 7) {
+    if constexpr (ABL == 0 || ABL == 1 || ABL == 4 || ABL >= 7) {
         s = wave_sum(s);
         ss = wave_sum(ss);
         if (lane == 0) {
@@ -184,6 +194,10 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
             unsigned long long *sl = ws->slots + (size_t)blockIdx.x * geo.slot_stride;
             __hip_atomic_store(sl, tag_bits(bs, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sl + 1, tag_bits(bss, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if constexpr (ABL == 8) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) store_n<VEC>((TS *)args.value_target, flat_k[k], nvalid_k[k], vt_keep[k]);
         }
         // lane l gathers blocks l, l+64, ...: only the granules still missing are re-polled
         constexpr int kPer = kMaxBlocks / kWave;
@@ -236,6 +250,12 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
             }
         }
     }
+    if constexpr (kVtWindow) {
+        if (wv != 0 || ABL == 9) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) store_n<VEC>((TS *)args.value_target, flat_k[k], nvalid_k[k], vt_keep[k]);
+        }
+    }
     __syncthreads();
     TS mean_s, std_s;
     mean_std<TS>(bc[0], bc[1], bc[2], geo.eps, mean_s, std_s);
@@ -246,7 +266,7 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
         for (int e = 0; e < V; ++e) out[e] = (adv_keep[k][e] - mean_s) / std_s;
         store_n<VEC>((TS *)args.advantage, flat_k[k], nvalid_k[k], out);
     }
-    if constexpr (kDeferVt) store_n<VEC>((TS *)args.value_target, flat_k[K - 1], nvalid_k[K - 1], vt_last);
+    if constexpr (kDeferVt && !kVtWindow) store_n<VEC>((TS *)args.value_target, flat_k[K - 1], nvalid_k[K - 1], vt_last);
     if constexpr (ABL == 7) {
         if (threadIdx.x == 0) {
             unsigned long long *dbg = (unsigned long long *)stats_out + 4 * blockIdx.x;
