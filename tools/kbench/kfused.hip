@@ -36,11 +36,10 @@ int main() {
     const int G = 256;
     FusedGeom geo{65536, 32, 32, 8, 65536 / 32, (double)N, 1e-4, 2};
     geo.slot_stride = 16;
-    for (int rep = 0; rep < 2; ++rep) {
-        run<4, 2>("full, vt not deferred", a, geo, ws, G, 300);
-        run<10, 2>("same, all loads up front", a, geo, ws, G, 300);
-        run<4, 4, 2>("full, vt not deferred", a, geo, ws, G, 300);
-        run<10, 4, 2>("same, all loads up front", a, geo, ws, G, 300);
+    for (int rep = 0; rep < 3; ++rep) {
+        run<0, 2>("full (product)", a, geo, ws, G, 500);
+        run<4, 2>("last vt deferred", a, geo, ws, G, 500);
+        run<1, 2>("no gather", a, geo, ws, G, 500);
     }
     for (int stride : {16}) {
       geo.slot_stride = stride;
