@@ -177,6 +177,55 @@ int trl_normalize(void *stream, int dtype, const void *x, int64_t n,
 int trl_moments(void *stream, int dtype, const void *x, int64_t n,
                 double *stats, void *workspace, size_t workspace_bytes);
 
+/*
+ * Cross-GPU sum of the moments -- the one collective of the path when the env dimension is sharded
+ * over GPUs (one process per GPU).  Replaces what `adv.mean()` / `adv.std()` over all elements
+ * (advantages.py:1459-1463) become on a sharded batch: an all-reduce(sum) of 3 doubles, i.e.
+ * torch.distributed.all_reduce(stats) over RCCL -- which stays the portable route and the
+ * checker.  This one is the low-latency route inside a node: every rank stores its 24 bytes
+ * directly into a mailbox in each peer's HBM over xGMI and polls its own mailbox (one 64-thread
+ * block, a few microseconds; RCCL's smallest all-reduce costs several times the GAE kernel).
+ *
+ * Set-up, once per process (the host side exchanges the handles with any out-of-band channel,
+ * e.g. torch.distributed.all_gather_object):
+ *   trl_xchg_local_init(&mailbox, handle)      allocate + zero this rank's mailbox (fine-grained
+ *                                              device memory on the current device), fill the
+ *                                              trl_xchg_handle_bytes()-byte IPC handle
+ *   trl_xchg_open(mailbox, handles, devices, rank, world, timeout_s, &comm)
+ *                                              handles: world * handle_bytes, in rank order;
+ *                                              devices: each rank's device ordinal (or NULL);
+ *                                              world <= 64, all ranks on one node
+ * Per step, on every rank, in the same order:
+ *   trl_xchg_allreduce_stats(stream, comm, stats)   stats: device double[3] {N, sum, sumsq},
+ *                                              summed over ranks IN PLACE, bit-identical on all
+ *                                              ranks (fixed rank order), N exact.  Asynchronous;
+ *                                              graph-capturable (the call counter lives on the device).
+ * A rank that waits longer than timeout_s (default 20) for a peer sets the comm's error word and
+ * writes NaNs: trl_xchg_error(comm) (synchronises the device) returns 1.
+ * trl_gae_normalize_xchg_fwd = trl_gae_normalize_fwd on a batch sharded over the comm's ranks: the
+ * moments are summed over all ranks INSIDE the launch (FUSED family: after the in-launch gather of
+ * the block moments, block 0 stores this GPU's totals into the peers' mailboxes and every block
+ * polls the local mailbox), so the whole sharded step stays one launch per GPU.  Shapes the FUSED
+ * family does not take run trl_gae_fwd -> trl_xchg_allreduce_stats -> trl_normalize.  `stats`
+ * receives the GLOBAL {N, sum, sumsq}.  Every rank must make the same sequence of calls on the comm.
+ */
+size_t trl_xchg_handle_bytes(void);
+int trl_xchg_local_init(void **mailbox, void *ipc_handle_out);
+int trl_xchg_open(void *mailbox, const void *ipc_handles, const int *peer_devices, int rank, int world,
+                  double timeout_s, void **comm_out);
+int trl_xchg_allreduce_stats(void *stream, void *comm, double *stats);
+int trl_xchg_set_timeout(void *comm, double timeout_s);
+int trl_xchg_error(void *comm);
+int trl_xchg_destroy(void *comm, void *mailbox);
+int trl_gae_normalize_xchg_fwd(void *stream, int val_dtype, int coef_dtype,
+                               const void *reward, const void *state_value, const void *next_state_value,
+                               const uint8_t *done, const uint8_t *terminated,
+                               const void *gamma_t, const void *lg_t,
+                               double gamma, double lmbda, double lg,
+                               int64_t O, int64_t T, int64_t I,
+                               void *advantage, void *value_target, double eps,
+                               double *stats, void *workspace, size_t workspace_bytes, void *comm, int algo);
+
 #ifdef __cplusplus
 }
 #endif

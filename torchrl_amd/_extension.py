@@ -53,6 +53,15 @@ _PROTOTYPES = {
                               _i64, _i64, _i64, _vp, _vp, _vp, _sz, _int]),
     "trl_normalize": (_int, [_vp, _int, _vp, _i64, _vp, _dbl, _vp]),
     "trl_moments": (_int, [_vp, _int, _vp, _i64, _vp, _vp, _sz]),
+    "trl_xchg_handle_bytes": (_sz, []),
+    "trl_xchg_local_init": (_int, [ctypes.POINTER(_vp), _vp]),
+    "trl_xchg_open": (_int, [_vp, _vp, ctypes.POINTER(_int), _int, _int, _dbl, ctypes.POINTER(_vp)]),
+    "trl_xchg_allreduce_stats": (_int, [_vp, _vp, _vp]),
+    "trl_xchg_set_timeout": (_int, [_vp, _dbl]),
+    "trl_xchg_error": (_int, [_vp]),
+    "trl_gae_normalize_xchg_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl,
+                                          _i64, _i64, _i64, _vp, _vp, _dbl, _vp, _vp, _sz, _vp, _int]),
+    "trl_xchg_destroy": (_int, [_vp, _vp]),
 }
 
 

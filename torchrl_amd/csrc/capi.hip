@@ -65,6 +65,15 @@ void *lb_region(void *workspace, size_t workspace_bytes, i64 O, i64 T, i64 I, si
 
 }  // namespace
 
+// error reporting for the other translation units' entry points (xchg_kernels.hip)
+int trl_internal_fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
 extern "C" {
 
 int trl_abi_version(void) { return TRL_ABI_VERSION; }
@@ -169,11 +178,11 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_
     return TRL_OK;
 }
 
-int trl_gae_normalize_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
-                          const void *next_state_value, const uint8_t *done, const uint8_t *terminated,
-                          const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
-                          int64_t O, int64_t T, int64_t I, void *advantage, void *value_target, double eps,
-                          double *stats, void *workspace, size_t workspace_bytes, int algo) {
+static int gae_normalize_impl(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
+                              const void *next_state_value, const uint8_t *done, const uint8_t *terminated,
+                              const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
+                              int64_t O, int64_t T, int64_t I, void *advantage, void *value_target, double eps,
+                              double *stats, void *workspace, size_t workspace_bytes, void *comm, int algo) {
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_normalize_fwd: bad dtype");
     if (int rc = check_dims("trl_gae_normalize_fwd", O, T, I)) return rc;
     if (!reward || !state_value || !next_state_value || !done || !terminated || !advantage || !value_target)
@@ -188,10 +197,10 @@ int trl_gae_normalize_fwd(void *stream, int val_dtype, int coef_dtype, const voi
     if (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_FUSED) {
         GaeArgs a{reward, state_value, next_state_value, done, terminated, gamma_t, lg_t, gamma, lmbda, lg,
                   O, T, I, advantage, value_target, nullptr};
-        LaunchResult res = launch_gae_fused(s, val_dtype, coef_dtype, a, eps, workspace, stats);
+        LaunchResult res = launch_gae_fused(s, val_dtype, coef_dtype, a, eps, workspace, stats, comm);
         if (res.status == 0) {
             if (int rc = check_launch("trl_gae_normalize_fwd(fused)")) return rc;
-            g_kernel = res.kernel;
+            g_kernel = comm ? "gae_fused_xchg" : res.kernel;
             return TRL_OK;
         }
         if (res.status != TRL_ERR_UNSUPPORTED) return fail(res.status, "trl_gae_normalize_fwd: fused launch rejected");
@@ -204,7 +213,30 @@ int trl_gae_normalize_fwd(void *stream, int val_dtype, int coef_dtype, const voi
                              lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, st, workspace, workspace_bytes,
                              algo == TRL_ALGO_FUSED ? TRL_ALGO_AUTO : algo))
         return rc;
+    if (comm)
+        if (int rc = trl_xchg_allreduce_stats(stream, comm, st)) return rc;
     return trl_normalize(stream, val_dtype, advantage, O * T * I, st, eps, advantage);
+}
+
+int trl_gae_normalize_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
+                          const void *next_state_value, const uint8_t *done, const uint8_t *terminated,
+                          const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
+                          int64_t O, int64_t T, int64_t I, void *advantage, void *value_target, double eps,
+                          double *stats, void *workspace, size_t workspace_bytes, int algo) {
+    return gae_normalize_impl(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated, gamma_t,
+                              lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, eps, stats, workspace,
+                              workspace_bytes, nullptr, algo);
+}
+
+int trl_gae_normalize_xchg_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
+                               const void *next_state_value, const uint8_t *done, const uint8_t *terminated,
+                               const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
+                               int64_t O, int64_t T, int64_t I, void *advantage, void *value_target, double eps,
+                               double *stats, void *workspace, size_t workspace_bytes, void *comm, int algo) {
+    if (!comm) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_normalize_xchg_fwd: null communicator");
+    return gae_normalize_impl(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated, gamma_t,
+                              lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, eps, stats, workspace,
+                              workspace_bytes, comm, algo);
 }
 
 int trl_normalize(void *stream, int dtype, const void *x, int64_t n, const double *stats, double eps, void *out) {

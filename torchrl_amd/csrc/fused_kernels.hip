@@ -27,6 +27,8 @@
 // share a workspace must not overlap (same stream, or external ordering).
 // Every spin is bounded (1 s wall clock): on timeout the error word is set and NaNs are written.
 #include "scan_core.h"
+#include "xchg.h"
+#include <cstdlib>
 
 namespace {
 
@@ -66,7 +68,7 @@ __device__ __forceinline__ double untag(unsigned long long b) { return __longlon
 // (both slower than storing it at once); 10 = every chunk's loads issued up front.
 template <class Op, bool VEC, bool WAVE_INDEP, int K, int ABL = 0, int TEAMS = kTeams>
 __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::Args args, FusedGeom geo, FusedWs *ws,
-                                                                  double *stats_out) {
+                                                                  double *stats_out, xchg::Dev xd = xchg::Dev{nullptr, nullptr, 0, 1, 0}) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
     constexpr int V = Op::V;
@@ -83,6 +85,8 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
     const int lane_off = tid * V;
     const unsigned T = (unsigned)geo.T;
     const unsigned tag = (ws->epoch + 1u) & 0xffu;  // written by the previous launch: visible across the kernel boundary
+    // batch sharded over GPUs: epoch of the cross-GPU mailbox, read before this block publishes
+    const unsigned xepoch = xd.local ? xd.local->epoch + 1u : 0u;
     unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
     if constexpr (ABL == 7) stamp0 = wall_clock64();
 
@@ -233,27 +237,32 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
         for (int j = 0; j < kPer; ++j)
             if (lane + kWave * j < (int)gridDim.x) { acc += untag(vs[j]); acq += untag(vq[j]); }
         acc = wave_sum(acc);
-        const double tot_ss = wave_sum(acq);
+        double tot_ss = wave_sum(acq);
+        double tot_n = geo.n_total;
+        bool x_ok = true;
+        if (xd.local) {
+            // second stage, across GPUs: block 0 stores this GPU's totals into every peer's mailbox over
+            // xGMI; every block then polls the LOCAL mailbox for all ranks' totals (xchg.h)
+            if (blockIdx.x == 0) xchg::send(xd, xepoch, lane, tot_n, acc, tot_ss);
+            x_ok = xchg::recv_sum(xd, xepoch, lane, tot_n, acc, tot_ss);
+        }
         if (lane == 0) {
             const double nan = __longlong_as_double(0x7ff8000000000000LL);
-            bc[0] = geo.n_total;
-            bc[1] = all_ok ? acc : nan;
-            bc[2] = all_ok ? tot_ss : nan;
+            const bool good = all_ok && x_ok;
+            bc[0] = tot_n;
+            bc[1] = good ? acc : nan;
+            bc[2] = good ? tot_ss : nan;
             if (!all_ok) ws->error = 1u;
+            if (!x_ok) xd.local->error = 1u;
             if (blockIdx.x == 0) {
                 ws->epoch = ws->epoch + 1u;  // every block has read the old epoch: all of them have published
+                if (xd.local) xd.local->epoch = xepoch;  // likewise: every block read it before publishing
                 if (stats_out && ABL != 7) {
-                    stats_out[0] = geo.n_total;
+                    stats_out[0] = tot_n;
                     stats_out[1] = bc[1];
                     stats_out[2] = bc[2];
                 }
             }
-        }
-    }
-    if constexpr (kVtWindow) {
-        if (wv != 0 || ABL == 9) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) store_n<VEC>((TS *)args.value_target, flat_k[k], nvalid_k[k], vt_keep[k]);
         }
     }
     __syncthreads();
@@ -292,12 +301,15 @@ int device_cus() {
 }
 
 template <class Op>
-LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *ws, double *stats_out) {
+LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *ws, double *stats_out, const xchg::Dev &xd) {
     constexpr int V = Op::V;
     const i64 chunk = (i64)kTeam * V;
     if (a.I != 1 || a.T > chunk) return LaunchResult{2, 0, nullptr};
     int G = device_cus();
     if (G <= 0) return LaunchResult{2, 0, nullptr};
+    // rehearsal hook: ranks that share one GPU (tools/xchg_check.py) must all be co-resident
+    static const int grid_cap = getenv("TRL_FUSED_GRID_CAP") ? atoi(getenv("TRL_FUSED_GRID_CAP")) : 0;
+    if (grid_cap > 0 && G > grid_cap) G = grid_cap;
     if (G > kMaxBlocks) G = kMaxBlocks;
     // R whole rows per chunk, R*T a multiple of V where possible (keeps every chunk start 16-B aligned)
     i64 R = chunk / a.T;
@@ -316,7 +328,7 @@ LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *w
     FusedGeom geo{a.O, a.T, (int)R, scan_lanes_for(a.T, V, wi), nchunks, (double)a.O * (double)a.T, eps, kSlotStride};
     const dim3 grid((unsigned)G), block(kFusedThreads);
     FusedWs *w = (FusedWs *)ws;
-#define TRL_FUSED(VEC, WI, KK) hipLaunchKernelGGL((gae_fused_kernel<Op, VEC, WI, KK>), grid, block, 0, s, a, geo, w, stats_out)
+#define TRL_FUSED(VEC, WI, KK) hipLaunchKernelGGL((gae_fused_kernel<Op, VEC, WI, KK>), grid, block, 0, s, a, geo, w, stats_out, xd)
 #define TRL_FUSED_K(VEC, WI) do { if (k_needed <= 2) TRL_FUSED(VEC, WI, 2); else TRL_FUSED(VEC, WI, 4); } while (0)
     if (vec) { if (wi) TRL_FUSED_K(true, true); else TRL_FUSED_K(true, false); }
     else     { if (wi) TRL_FUSED_K(false, true); else TRL_FUSED_K(false, false); }
@@ -327,10 +339,11 @@ LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *w
 
 }  // namespace
 
-LaunchResult launch_gae_fused(hipStream_t s, int vdt, int cdt, const GaeArgs &a, double eps, void *ws, double *stats_out) {
-    if (vdt == 0 && cdt == 0) return launch_fused_t<GaeOp<float, float, 4>>(s, a, eps, ws, stats_out);
-    if (vdt == 1 && cdt == 1) return launch_fused_t<GaeOp<double, double, 2>>(s, a, eps, ws, stats_out);
-    if (vdt == 1 && cdt == 0) return launch_fused_t<GaeOp<double, float, 2>>(s, a, eps, ws, stats_out);
-    if (vdt == 0 && cdt == 1) return launch_fused_t<GaeOp<float, double, 4>>(s, a, eps, ws, stats_out);
+LaunchResult launch_gae_fused(hipStream_t s, int vdt, int cdt, const GaeArgs &a, double eps, void *ws, double *stats_out, void *comm) {
+    const xchg::Dev xd = xchg_dev_of(comm);
+    if (vdt == 0 && cdt == 0) return launch_fused_t<GaeOp<float, float, 4>>(s, a, eps, ws, stats_out, xd);
+    if (vdt == 1 && cdt == 1) return launch_fused_t<GaeOp<double, double, 2>>(s, a, eps, ws, stats_out, xd);
+    if (vdt == 1 && cdt == 0) return launch_fused_t<GaeOp<double, float, 2>>(s, a, eps, ws, stats_out, xd);
+    if (vdt == 0 && cdt == 1) return launch_fused_t<GaeOp<float, double, 4>>(s, a, eps, ws, stats_out, xd);
     return LaunchResult{1, 0, nullptr};
 }

@@ -12,3 +12,4 @@ from torchrl_amd.objectives.value.advantages import (  # noqa: F401
     ValueEstimatorBase,
     VTrace,
 )
+from torchrl_amd.objectives.value.stats_exchange import StatsExchange  # noqa: F401,E402

@@ -446,13 +446,15 @@ class GAE(ValueEstimatorBase):
     Keyword Args: ``gamma``, ``lmbda``, ``value_network`` (``None`` to read ``state_value`` and
     ``("next", "state_value")`` from the data), ``average_gae`` (normalise with eps 1e-4),
     ``differentiable``, ``vectorized``, ``skip_existing``, ``shifted``, ``device``, ``time_dim``;
-    extension: ``process_group`` (all-reduce the moments of a batch sharded over ranks).
+    extensions for a batch sharded over ranks (one process per GPU): ``process_group`` (RCCL
+    all-reduce of the fp64 moments) or ``stats_exchange`` (a :class:`StatsExchange`: the moments
+    cross the GPUs inside the launch, intra-node).
     """
 
     def __init__(self, *, gamma, lmbda, value_network, average_gae: bool = False, differentiable: bool = False,
                  vectorized: Optional[bool] = None, skip_existing: Optional[bool] = None, advantage_key: NestedKey = None,
                  value_target_key: NestedKey = None, value_key: NestedKey = None, shifted: bool = False, device=None,
-                 time_dim: Optional[int] = None, process_group=None):
+                 time_dim: Optional[int] = None, process_group=None, stats_exchange=None):
         super().__init__(shifted=shifted, value_network=value_network, differentiable=differentiable,
                          advantage_key=advantage_key, value_target_key=value_target_key, value_key=value_key,
                          skip_existing=skip_existing, device=device)
@@ -462,6 +464,7 @@ class GAE(ValueEstimatorBase):
         self.vectorized = vectorized
         self.time_dim = time_dim
         self.process_group = process_group
+        self.stats_exchange = stats_exchange
 
     def _inputs(self, data, params, target_params, time_dim):
         self._check_dims(data)
@@ -481,7 +484,8 @@ class GAE(ValueEstimatorBase):
             gamma, lmbda, value, next_value, reward, done, terminated, td = self._inputs(data, params, target_params, time_dim)
             if self.average_gae:
                 adv, value_target = F.gae_normalized(gamma, lmbda, value, next_value, reward, done, terminated, eps=1e-4,
-                                                     time_dim=td, group=self.process_group)
+                                                     time_dim=td, group=self.process_group,
+                                                     exchange=None if self.differentiable else self.stats_exchange)
             else:
                 fn = F.vec_generalized_advantage_estimate if self.vectorized else F.generalized_advantage_estimate
                 adv, value_target = fn(gamma, lmbda, value, next_value, reward, done=done, terminated=terminated, time_dim=td)

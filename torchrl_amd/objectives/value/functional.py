@@ -26,6 +26,7 @@ have no counterpart here.
 from __future__ import annotations
 
 import ctypes
+import struct
 import math
 import warnings
 from dataclasses import dataclass
@@ -146,9 +147,17 @@ def _expand_coef(x: torch.Tensor, shape, time_dim: int) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------
 # coefficient rounding
 # ---------------------------------------------------------------------------------------------
+_F32 = struct.Struct("f")
+
+
 def _round_to(value: float, dtype: torch.dtype) -> float:
     if dtype == torch.float64:
         return float(value)
+    if dtype == torch.float32:
+        try:  # round-to-nearest-even double -> float, as torch.tensor(value, dtype=float32) does
+            return _F32.unpack(_F32.pack(value))[0]
+        except OverflowError:
+            pass  # beyond FLT_MAX: torch gives +-inf
     return float(torch.tensor(value, dtype=dtype))
 
 
@@ -196,7 +205,8 @@ def _require_hip(t: torch.Tensor):
 
 
 def _val(t: torch.Tensor, dtype, device=None) -> torch.Tensor:
-    t = t.detach()
+    if t.requires_grad:
+        t = t.detach()
     if t.dtype != dtype:
         t = t.to(dtype)
     if device is not None and t.device != device:
@@ -205,7 +215,6 @@ def _val(t: torch.Tensor, dtype, device=None) -> torch.Tensor:
 
 
 def _mask(m: torch.Tensor, shape, device=None) -> torch.Tensor:
-    m = m.detach()
     if m.dtype != torch.bool:
         m = m != 0
     if tuple(m.shape) != tuple(shape):
@@ -349,19 +358,24 @@ def _launch_gae(c: _GaeCall, want_stats: bool = False, algo: int = ALGO_AUTO, ou
     return adv, vt, stats
 
 
-def _launch_gae_normalize(c: _GaeCall, eps: float, algo: int = ALGO_AUTO, out=None, want_stats: bool = False):
-    """GAE + normalisation over all elements in one C-ABI call (single launch when eligible)."""
+def _launch_gae_normalize(c: _GaeCall, eps: float, algo: int = ALGO_AUTO, out=None, want_stats: bool = False, exchange=None):
+    """GAE + normalisation over all elements in one C-ABI call (single launch when eligible).
+    ``exchange`` (:class:`StatsExchange`): the batch is sharded over its ranks; the moments are
+    summed across GPUs inside the launch (trl_gae_normalize_xchg_fwd)."""
     lib = _extension.get_lib()
     _require_hip(c.next_value)
     dev = c.next_value.device
     adv, vt = out if out is not None else (torch.empty(c.shape, dtype=c.vdt, device=dev), torch.empty(c.shape, dtype=c.vdt, device=dev))
     ws = _workspace(lib, dev, c.O, c.T, c.I)
     stats = torch.empty(3, dtype=torch.float64, device=dev) if want_stats else None
-    with torch.cuda.device(dev):
-        rc = lib.trl_gae_normalize_fwd(
-            _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.value), _ptr(c.next_value),
+    head = (_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.value), _ptr(c.next_value),
             _ptr(c.done), _ptr(c.terminated), _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg,
-            c.O, c.T, c.I, _ptr(adv), _ptr(vt), float(eps), _ptr(stats), _ptr(ws), ws.numel(), algo)
+            c.O, c.T, c.I, _ptr(adv), _ptr(vt), float(eps), _ptr(stats), _ptr(ws), ws.numel())
+    with torch.cuda.device(dev):
+        if exchange is not None:
+            rc = lib.trl_gae_normalize_xchg_fwd(*head, exchange.comm, algo)
+        else:
+            rc = lib.trl_gae_normalize_fwd(*head, algo)
     _extension.check(rc, lib)
     if c.out_dtype != c.vdt:
         adv, vt = adv.to(c.out_dtype), vt.to(c.out_dtype)
@@ -540,12 +554,14 @@ class PreparedStep:
 
 
 def prepare_gae_step(call: _GaeCall, eps: Optional[float] = None, *, normalize: bool = True, want_stats: bool = False,
-                     algo: int = ALGO_AUTO) -> PreparedStep:
+                     algo: int = ALGO_AUTO, exchange=None) -> PreparedStep:
     """Bind GAE (+ normalisation) on ``call``'s tensors to the current stream.
 
     ``normalize=True``: one ``trl_gae_normalize_fwd`` call (single launch when eligible).
     ``normalize=False, want_stats=True``: ``trl_gae_fwd`` writing the fp64 moments to
-    ``PreparedStep.stats`` -- the caller all-reduces them and runs :func:`prepare_normalize`'s step."""
+    ``PreparedStep.stats`` -- the caller all-reduces them and runs :func:`prepare_normalize`'s step.
+    ``exchange`` (:class:`StatsExchange`) with ``normalize=True``: ``trl_gae_normalize_xchg_fwd`` -- the
+    moments are summed across the exchange's ranks inside the launch."""
     lib = _extension.get_lib()
     _require_hip(c := call.next_value)
     dev = c.device
@@ -556,11 +572,13 @@ def prepare_gae_step(call: _GaeCall, eps: Optional[float] = None, *, normalize: 
     head = (_stream(dev), _DT[call.vdt], _DT[call.cdt], _ptr(call.reward), _ptr(call.value), _ptr(call.next_value),
             _ptr(call.done), _ptr(call.terminated), _ptr(call.gamma_t), _ptr(call.lg_t), call.gamma, call.lmbda, call.lg,
             call.O, call.T, call.I, _ptr(adv), _ptr(vt))
-    if normalize:
+    if normalize and exchange is not None:  # batch sharded over the exchange's ranks: still one C-ABI call
+        calls = [(lib.trl_gae_normalize_xchg_fwd, head + (float(eps), _ptr(stats), _ptr(ws), ws.numel(), exchange.comm, algo))]
+    elif normalize:
         calls = [(lib.trl_gae_normalize_fwd, head + (float(eps), _ptr(stats), _ptr(ws), ws.numel(), algo))]
     else:
         calls = [(lib.trl_gae_fwd, head + (_ptr(stats), _ptr(ws), ws.numel(), algo))]
-    return PreparedStep(calls, (call, ws), (adv, vt), stats)
+    return PreparedStep(calls, (call, ws, exchange), (adv, vt), stats)
 
 
 def prepare_normalize(x: torch.Tensor, stats: torch.Tensor, eps: float) -> PreparedStep:
@@ -572,7 +590,7 @@ def prepare_normalize(x: torch.Tensor, stats: torch.Tensor, eps: float) -> Prepa
 
 
 def gae_normalized(gamma, lmbda, state_value, next_state_value, reward, done, terminated=None, *, eps: float = 1e-4,
-                   time_dim=-2, group=None, distributed: bool = False, algo: int = ALGO_AUTO):
+                   time_dim=-2, group=None, distributed: bool = False, algo: int = ALGO_AUTO, exchange=None):
     """GAE followed by ``(adv - adv.mean()) / adv.std().clamp_min(eps)`` over all elements: what
     ``GAE(average_gae=True)`` computes (reference: advantages.py:1436-1463).  Returns
     ``(normalised advantage, value_target)``.
@@ -580,7 +598,9 @@ def gae_normalized(gamma, lmbda, state_value, next_state_value, reward, done, te
     Single GPU: one C-ABI call, one kernel launch when the shape is eligible (FUSED family).
     ``distributed`` / ``group``: the batch is sharded over ranks along the env dimension; the
     fp64 moments are all-reduced (one 24-byte RCCL all-reduce) between the GAE kernel and the
-    scale pass, so every rank normalises with the global statistics."""
+    scale pass, so every rank normalises with the global statistics.  ``exchange``
+    (:class:`StatsExchange`, intra-node): the moments cross the GPUs inside the launch instead
+    (peer-to-peer mailbox stores over xGMI) and the sharded step stays one launch per GPU."""
     call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
     if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
         # differentiable path: GAE through the autograd function, normalisation as the reference's torch ops
@@ -588,6 +608,9 @@ def gae_normalized(gamma, lmbda, state_value, next_state_value, reward, done, te
         adv, vt = _GaeFunction.apply(state_value, next_state_value, reward, call, None)
         return (adv - adv.mean()) / adv.std().clamp_min(eps), vt
     dist = torch.distributed
+    if exchange is not None:
+        adv, vt, _ = _launch_gae_normalize(call, eps, algo=algo, exchange=exchange)
+        return adv, vt
     if (distributed or group is not None) and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         adv, vt, stats = _launch_gae(call, want_stats=True, algo=ALGO_AUTO if algo == ALGO_FUSED else algo)
         dist.all_reduce(stats, group=group)
