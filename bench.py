@@ -4,9 +4,12 @@
 
 One "step" is one pass of the hot path over one batch of synthetic rollouts already resident in
 HBM.  N = 1: trl_gae_normalize_fwd -- ONE launch (fused delta + scan + value_target + fp64 moments
-+ in-launch gather + normalisation).  N > 1: trl_gae_fwd (scan + moments) -> one RCCL all-reduce of
-the 3 fp64 moments -> trl_normalize (in place).  Every rank owns a full [65536 x 32] batch (weak
-scaling: the env dimension is sharded, nothing else is exchanged).  Rank 0 prints ONE JSON line
++ in-launch gather + normalisation).  N > 1: every rank owns a full [65536 x 32] batch (weak
+scaling: the env dimension is sharded) and the only exchange is the sum of the 3 fp64 moments.
+Preferred route: trl_gae_normalize_xchg_fwd -- still ONE launch per GPU, the moments cross the GPUs
+inside it (peer-to-peer mailbox stores over xGMI); it is validated against the RCCL route on the
+live topology first and used only if every rank agrees.  Fallback: trl_gae_fwd (scan + moments) ->
+RCCL all-reduce -> trl_normalize.  Rank 0 prints ONE JSON line
 (schema in the task contract) with `roofline` for the dominant kernel and `cpu_baseline` (the CPU
 oracle timed on this host, N = 1 only).
 """
@@ -71,8 +74,8 @@ def cpu_baseline(r, v, nv, done, term):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)  # ~20 ms of GPU time: long enough for the clocks to settle
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -86,6 +89,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # TRL_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs than ranks
         # (ranks share devices; gloo stages the 24-byte all-reduce through the host).  Default: RCCL.
+        # (set TRL_FUSED_GRID_CAP = 256 / ranks-per-GPU there so that the ranks' kernels are co-resident)
         backend = os.environ.get("TRL_BENCH_BACKEND", "nccl")
         local_rank = local_rank % torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
@@ -99,34 +103,71 @@ def main():
     r, v, nv, done, term = make_inputs(dev, seed=rank)
     call = F._prepare_gae(GAMMA, LMBDA, v, nv, r, done, term, -2)  # host canonicalisation: views only, no copies
 
-    # HIP events on the launch stream.  N = 1: one kernel per step, so two events around the whole
-    # timed region give that kernel's average launch-to-launch duration without per-step host work.
-    # N > 1: per-step events around the GAE kernel (the collective dominates the step there).
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps if dist else 1)]
-
     # The step is bound once to fixed buffers (a training loop keeps its rollout buffers in place):
-    # the timed region contains the C-ABI calls (kernels) and, for N > 1, the collective -- nothing else.
+    # the timed region contains the C-ABI calls (kernels) and, on the fallback route, the collective.
+    collective = "none"
+    norm = None
     if dist:
+        def all_reduce_stats(st):
+            if backend == "gloo":  # rehearsal: gloo has no device tensors
+                h = st.cpu()
+                td.all_reduce(h)
+                st.copy_(h)
+            else:
+                td.all_reduce(st)
+
         gae = F.prepare_gae_step(call, normalize=False, want_stats=True)
         norm = F.prepare_normalize(gae.outputs[0], gae.stats, EPS)
+        gae.run()
+        all_reduce_stats(gae.stats)
+        norm.run()
+        ref_adv = gae.outputs[0].clone()
+        collective = "all_reduce(3 x f64) over " + ("RCCL" if backend == "nccl" else backend)
+        if os.environ.get("TRL_BENCH_EXCHANGE", "1") != "0":
+            from torchrl_amd.objectives.value.stats_exchange import StatsExchange
+
+            ex = StatsExchange.create(timeout_s=5.0)  # self-tested against the process group's all-reduce
+            good = False
+            if ex is not None:
+                fused = F.prepare_gae_step(call, EPS, normalize=True, exchange=ex)
+                for _ in range(3):
+                    fused.run()
+                torch.cuda.synchronize()
+                good = (not ex.error()) and bool(torch.allclose(fused.outputs[0], ref_adv, rtol=2e-6, atol=2e-6))
+            votes = [None] * world
+            td.all_gather_object(votes, good)
+            if all(votes):
+                ex.set_timeout(20.0)
+                gae, norm = fused, None
+                collective = "in-launch peer-to-peer mailbox exchange (3 x f64 per rank over xGMI), validated against " + collective
+            elif rank == 0:
+                print(f"bench: exchange route not used (votes {votes}); falling back to {collective}", file=sys.stderr)
     else:
         gae = F.prepare_gae_step(call, EPS, normalize=True)  # one launch (FUSED family)
 
-    def step(k=None):
-        if not dist:
-            gae.run()
-            return gae.outputs
-        if k is not None:
-            ev[k][0].record()
+    # HIP events on the launch stream: two events around the whole timed region.  With one kernel per
+    # step (N = 1, and N > 1 on the exchange route) that is the kernel's average launch-to-launch
+    # duration without per-step host work; on the RCCL fallback route it is the whole step.
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    def step():
         gae.run()
-        if k is not None:
-            ev[k][1].record()
-        td.all_reduce(gae.stats)
-        norm.run()
+        if norm is not None:
+            all_reduce_stats(gae.stats)
+            norm.run()
         return gae.outputs
 
     gae.run()
     kernel_name = F.last_kernel()  # the dominant kernel: the GAE entry point's
+    gae_only_ms = None
+    if norm is not None:  # fallback route: time the GAE kernel on its own (untimed region)
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(50):
+            gae.run()
+        ev[1].record()
+        torch.cuda.synchronize()
+        gae_only_ms = ev[0].elapsed_time(ev[1]) / 50
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -134,12 +175,10 @@ def main():
         td.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if not dist:
-        ev[0][0].record()
+    ev[0].record()
     for k in range(args.steps):
-        step(k)
-    if not dist:
-        ev[0][1].record()
+        step()
+    ev[1].record()
     t_host = time.perf_counter() - t0  # host time to enqueue K steps
     torch.cuda.synchronize()
     if dist:
@@ -153,7 +192,7 @@ def main():
 
     if rank == 0:
         n_trans = O_ENVS * T_STEPS
-        gae_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps  # HIP events on the launch stream (see above)
+        gae_ms = gae_only_ms if gae_only_ms is not None else ev[0].elapsed_time(ev[1]) / args.steps  # HIP events on the launch stream
         achieved = n_trans * BYTES_PER_TRANSITION / (gae_ms * 1e-3) / 1e9
         out = {
             "metric": "GAE transitions/sec + % HBM roofline at 65536x32",
@@ -170,7 +209,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"GAE(gamma={GAMMA},lmbda={LMBDA})+normalise(eps={EPS}) [{O_ENVS} envs x {T_STEPS} steps] fp32 per GPU",
                        "per_gpu_transitions": n_trans, "parallelism": f"env-sharded x{world}",
-                       "collective": "all_reduce(3 x f64)" if dist else "none"},
+                       "collective": collective},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": PMC_TRAFFIC_BYTES_FUSED if kernel_name == "gae_fused" else None, "kernel": kernel_name,
