@@ -83,6 +83,23 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = world > 1
+    probe_ok = False
+    if dist and os.environ.get("TRL_BENCH_EXCHANGE", "1") != "0":
+        # The exchange route stores into peers' HBM through IPC mappings: it is tried first in a child
+        # process per rank (own gloo group over a file store), BEFORE this process touches the GPU, so
+        # that an interconnect that misbehaves costs a probe, not the benchmark.
+        import subprocess
+
+        store = f"/tmp/trl_xchg_probe_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+        try:
+            pr = subprocess.run([sys.executable, "-m", "torchrl_amd.objectives.value.stats_exchange", store], cwd=ROOT,
+                                env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")),
+                                capture_output=True, text=True, timeout=240)
+            probe_ok = pr.returncode == 0
+            if not probe_ok and rank == 0:
+                print("bench: exchange probe failed:\n" + pr.stdout[-2000:] + pr.stderr[-2000:], file=sys.stderr)
+        except Exception as e:  # noqa: BLE001
+            print(f"bench: exchange probe did not finish: {e}", file=sys.stderr)
     if dist:
         import torch.distributed as td
 
@@ -123,7 +140,9 @@ def main():
         norm.run()
         ref_adv = gae.outputs[0].clone()
         collective = "all_reduce(3 x f64) over " + ("RCCL" if backend == "nccl" else backend)
-        if os.environ.get("TRL_BENCH_EXCHANGE", "1") != "0":
+        probes = [None] * world
+        td.all_gather_object(probes, probe_ok)
+        if all(probes):
             from torchrl_amd.objectives.value.stats_exchange import StatsExchange
 
             ex = StatsExchange.create(timeout_s=5.0)  # self-tested against the process group's all-reduce
@@ -142,6 +161,10 @@ def main():
                 collective = "in-launch peer-to-peer mailbox exchange (3 x f64 per rank over xGMI), validated against " + collective
             elif rank == 0:
                 print(f"bench: exchange route not used (votes {votes}); falling back to {collective}", file=sys.stderr)
+        elif rank == 0:
+            print(f"bench: exchange route not used (probe results {probes}); using {collective}", file=sys.stderr)
+        if rank == 0 and os.path.exists(f"/tmp/trl_xchg_probe_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"):
+            os.remove(f"/tmp/trl_xchg_probe_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
     else:
         gae = F.prepare_gae_step(call, EPS, normalize=True)  # one launch (FUSED family)
 

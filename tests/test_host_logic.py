@@ -148,3 +148,19 @@ def test_transpose_time_decorator_contract():
     assert f(torch.randn(7), time_dim=-1).shape == (7,)
     with pytest.raises(RuntimeError, match="not compatible"):
         f(torch.randn(7), time_dim=-3)
+
+
+def test_library_binds_to_torchs_hip_runtime_whatever_the_import_order():
+    """Importing the package before torch must not bring a second HIP runtime into the process
+    (the library's RUNPATH names the system copy; torch ships its own under the same SONAME)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torchrl_amd, torch\n"
+            "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+            "print(len(libs), libs)\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == "1", out.stdout

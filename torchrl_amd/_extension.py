@@ -78,6 +78,11 @@ def _load():
     if _lib is not None:
         return _lib
     try:
+        # torch first: the library must bind to the HIP runtime torch ships (same SONAME,
+        # libamdhip64.so.7).  Loaded before torch, it would pull in the system copy through its
+        # RUNPATH and the process would hold two HIP runtimes that do not see each other's state.
+        import torch  # noqa: F401
+
         lib = ctypes.CDLL(_LIB_PATH)
         for name, (res, args) in _PROTOTYPES.items():
             fn = getattr(lib, name)

@@ -74,7 +74,12 @@ size_t trl_xchg_handle_bytes(void) { return sizeof(hipIpcMemHandle_t); }
 int trl_xchg_local_init(void **mailbox, void *ipc_handle_out) {
     if (!mailbox || !ipc_handle_out) return trl_internal_fail(TRL_ERR_INVALID_ARGUMENT, "trl_xchg_local_init: null argument");
     void *p = nullptr;
-    hipError_t e = hipExtMallocWithFlags(&p, sizeof(XchgMailbox), hipDeviceMallocFinegrained);
+    int dev = 0;
+    hipError_t e = hipInit(0);  // this may be the first HIP call of the process
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipSetDevice(dev);
+    if (e != hipSuccess) return trl_internal_fail(TRL_ERR_LAUNCH, "trl_xchg_local_init: HIP runtime: %s", hipGetErrorString(e));
+    e = hipExtMallocWithFlags(&p, sizeof(XchgMailbox), hipDeviceMallocFinegrained);
     if (e != hipSuccess) return trl_internal_fail(TRL_ERR_LAUNCH, "trl_xchg_local_init: hipExtMallocWithFlags: %s", hipGetErrorString(e));
     e = hipMemset(p, 0, sizeof(XchgMailbox));
     if (e == hipSuccess) e = hipDeviceSynchronize();

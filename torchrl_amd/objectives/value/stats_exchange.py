@@ -28,6 +28,7 @@ class StatsExchange:
 
         self._lib = lib = _extension.get_lib()
         self._comm = self._mailbox = None
+        torch.cuda.init()  # the device context must exist before the library's first HIP call
         self.group = group
         self.rank, self.world = td.get_rank(group), td.get_world_size(group)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -67,7 +68,10 @@ class StatsExchange:
         try:
             ex = cls(group, device, timeout_s=timeout_s)
             good = True
-        except Exception:  # noqa: BLE001 -- every rank must reach the vote below
+        except Exception as e:  # noqa: BLE001 -- every rank must reach the vote below
+            import warnings
+
+            warnings.warn(f"StatsExchange could not be set up: {type(e).__name__}: {e}")
             ex, good = None, False
         votes = [None] * td.get_world_size(group)
         td.all_gather_object(votes, good, group=group)
@@ -145,3 +149,62 @@ class StatsExchange:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+def _probe_main(store_path: str) -> int:
+    """Crash-isolated check of the exchange on the live topology (run as a child process per rank,
+    ``python -m torchrl_amd.objectives.value.stats_exchange <file-store path>`` with RANK / WORLD_SIZE /
+    LOCAL_RANK in the environment): builds a gloo group over a file store, creates the exchange
+    (self-tested against gloo's all-reduce) and runs a small sharded GAE + normalise through the
+    in-launch cross-GPU stage against the three-launch route.  Exit code 0 = every rank passed.  A
+    caller that must not die with a misbehaving interconnect (bench.py) looks at the exit code only."""
+    import os
+
+    import torch.distributed as td
+
+    from . import functional as F
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.zeros(1, device=dev)  # device context up before anything else
+    store = td.FileStore(store_path, world)
+    td.init_process_group("gloo", store=store, rank=rank, world_size=world)
+    good = False
+    try:
+        ex = StatsExchange.create(device=dev, timeout_s=5.0)
+        if ex is not None:
+            g = torch.Generator().manual_seed(rank)
+            shape = (4096, 32, 1)
+            r, v, nv = (torch.randn(shape, generator=g).to(dev) for _ in range(3))
+            done = (torch.rand(shape, generator=g) < 0.02).to(dev)
+            call = F._prepare_gae(0.99, 0.95, v, nv, r, done, done, -2)
+            adv0, _, st = F._launch_gae(call, want_stats=True)
+            h = st.cpu()
+            td.all_reduce(h)
+            ref = F.normalize_(adv0.clone(), h.to(dev), 1e-4)
+            good = True
+            for _ in range(3):
+                adv, _, _ = F._launch_gae_normalize(call, 1e-4, exchange=ex)
+                good = good and bool(torch.allclose(adv, ref, rtol=2e-6, atol=2e-6))
+            err = ex.error()
+            if not good or err:
+                print(f"exchange probe rank {rank}: mismatch (max abs diff {float((adv - ref).abs().max())}, timeout {err})", flush=True)
+            good = good and not err
+            ex.close()
+        else:
+            print(f"exchange probe rank {rank}: StatsExchange.create() declined", flush=True)
+    except Exception as e:  # noqa: BLE001
+        print(f"exchange probe rank {rank}: {type(e).__name__}: {e}", flush=True)
+        good = False
+    votes = [None] * world
+    td.all_gather_object(votes, good)
+    td.destroy_process_group()
+    return 0 if all(votes) else 3
+
+
+if __name__ == "__main__":
+    import sys
+
+    sys.exit(_probe_main(sys.argv[1]))
