@@ -178,6 +178,26 @@ int trl_moments(void *stream, int dtype, const void *x, int64_t n,
                 double *stats, void *workspace, size_t workspace_bytes);
 
 /*
+ * Per-group statistics and normalisation.
+ * Replaces: _standardize(input, exclude_dims) (torchrl/_utils.py:875-936; PPO's advantage
+ *           normalisation, torchrl/objectives/ppo.py:688, 975, 1282): mean / unbiased std over the
+ *           dims NOT excluded, one pair per index of the excluded dims ("keep the agent dimension
+ *           independent"), then (x - mean) / std.clamp_min(eps).
+ * x is seen as a contiguous (outer, G, inner) array: element f = (o*G + g)*inner + j belongs to
+ * group g (the host merges adjacent dims, or permutes, into this pattern); G <= 65535.
+ * trl_moments_grouped: stats[3*g .. 3*g+2] = {outer*inner, sum, sumsq} of group g (fp64, fixed order);
+ *   needs `workspace` of trl_grouped_workspace_bytes().  A batch sharded over GPUs all-reduces
+ *   the G*3 doubles before normalising.
+ * trl_normalize_grouped: out = (x - mean_g) / max(std_g, eps), mean / std rounded to `dtype`
+ *   as in trl_normalize.  out may alias x.
+ */
+size_t trl_grouped_workspace_bytes(int64_t outer, int64_t G, int64_t inner);
+int trl_moments_grouped(void *stream, int dtype, const void *x, int64_t outer, int64_t G, int64_t inner,
+                        double *stats, void *workspace, size_t workspace_bytes);
+int trl_normalize_grouped(void *stream, int dtype, const void *x, int64_t outer, int64_t G, int64_t inner,
+                          const double *stats, double eps, void *out);
+
+/*
  * Cross-GPU sum of the moments -- the one collective of the path when the env dimension is sharded
  * over GPUs (one process per GPU).  Replaces what `adv.mean()` / `adv.std()` over all elements
  * (advantages.py:1459-1463) become on a sharded batch: an all-reduce(sum) of 3 doubles, i.e.

@@ -1,0 +1,112 @@
+"""`_standardize` (reference: torchrl/_utils.py:875-936; reference test: test_cost.py:16166-16176).
+CPU: the numpy oracle against the golden vectors generated from the reference
+(tools/gen_golden_standardize.py), and the host-side validation.  GPU (-m gpu): the HIP path
+(trl_moments_grouped / trl_normalize_grouped through the C ABI) against the same goldens and the oracle.
+Tolerance: torch reduces mean / std in the storage dtype with an internal order, the HIP path and the
+oracle in fp64, so fp32 agrees to ~1e-6 relative (stated below), fp64 to 1e-12."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import value_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MAN = json.load(open(os.path.join(HERE, "golden", "standardize_manifest.json")))
+Z = np.load(os.path.join(HERE, "golden", "standardize.npz"))
+CASES = MAN["cases"]
+IDS = [f"{c['id']}-{'x'.join(map(str, c['shape']))}-{c['dtype']}-ex{c['exclude_dims']}" for c in CASES]
+
+
+def tol(dtype):
+    return dict(rtol=3e-6, atol=3e-6) if dtype == torch.float32 else dict(rtol=1e-12, atol=1e-12)
+
+
+def arrays(c):
+    g = lambda k: torch.from_numpy(Z[f"{c['id']}.{k}"]) if f"{c['id']}.{k}" in Z.files else None
+    return g("x"), g("out"), g("mean"), g("std")
+
+
+@pytest.mark.parametrize("c", CASES, ids=IDS)
+def test_oracle_matches_reference_goldens(c):
+    x, ref, mean, std = arrays(c)
+    if mean is not None or std is not None or "mean" in c:
+        pytest.skip("caller-provided statistics: no reduction to restate")
+    torch.testing.assert_close(O.standardize(x, c["exclude_dims"], c["eps"]), ref, **tol(x.dtype))
+
+
+def test_reference_test_case_closed_form():
+    """test_cost.py:16166-16176 restated on the oracle."""
+    t = torch.arange(3 * 4 * 5 * 6, dtype=torch.float32).view(3, 4, 5, 6)
+    want = (t - t.mean((0, 2), keepdim=True)) / t.std((0, 2), keepdim=True).clamp(1e-6)
+    torch.testing.assert_close(O.standardize(t, (1, 3)), want, **tol(torch.float32))
+    torch.testing.assert_close(O.standardize(t, ()), (t - t.mean()) / t.std(), **tol(torch.float32))
+
+
+def test_validation_matches_reference():
+    from torchrl_amd._utils import _standardize
+
+    x = torch.randn(16, 5, 2)
+    table = {e["name"]: e for e in MAN["errors"]}
+    for name, ex in (("repeated", (1, 1)), ("out_of_bounds", (3,)), ("negative_out_of_bounds", (-4,))):
+        with pytest.raises(ValueError) as ei:
+            _standardize(x, ex)
+        assert str(ei.value) == table[name]["message"]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = _standardize(x, (0, 1, 2))
+    assert out is x and str(w[0].message) == table["all_excluded"]["message"]
+    # caller-provided statistics never reach the library (test_cost.py:16173)
+    t = torch.arange(24, dtype=torch.float32).view(2, 3, 4)
+    torch.testing.assert_close(_standardize(t, (), -1, 2), (t + 1) / 2)
+
+
+def test_grouped_pattern():
+    from torchrl_amd._utils import _grouped_pattern
+
+    assert _grouped_pattern([32, 10, 5, 1], [2]) == (320, 5, 1, None)
+    assert _grouped_pattern([32, 10, 5, 1], [2, 3]) == (320, 5, 1, None)
+    assert _grouped_pattern([32, 10, 5, 1], [0]) == (1, 32, 50, None)
+    assert _grouped_pattern([6, 4, 3, 2, 5], [1, 3]) == (1, 8, 90, [1, 3, 0, 2, 4])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", CASES, ids=IDS)
+def test_hip_matches_reference_goldens(c):
+    from torchrl_amd._utils import _standardize
+
+    x, ref, mean, std = arrays(c)
+    dev = "cuda:0"
+    kw = {}
+    if mean is not None:
+        kw["mean"] = mean.to(dev)
+    elif "mean" in c:
+        kw["mean"] = c["mean"]
+    if std is not None:
+        kw["std"] = std.to(dev)
+    elif "std" in c:
+        kw["std"] = c["std"]
+    out = _standardize(x.to(dev), tuple(c["exclude_dims"]), eps=c["eps"], **kw)
+    assert out.shape == ref.shape and out.dtype == ref.dtype and out.is_contiguous()
+    torch.testing.assert_close(out.cpu(), ref, **tol(ref.dtype))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,ex", [((4096, 100, 5, 1), (-2,)), ((65536, 32, 1), (1,)), ((8, 3000, 7), (0, 2)), ((3, 70000), (0,)),
+                                      ((5000, 3), (0,)), ((1, 1, 9), (2,))])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_hip_matches_oracle_larger_shapes(shape, ex, dtype):
+    """Multi-agent rollout shapes (agent dim kept independent), many groups (> LDS table), permuted
+    (non-adjacent) excluded dims, single-element groups (std = NaN as torch gives)."""
+    from torchrl_amd._utils import _standardize
+
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(shape, generator=g, dtype=torch.float64) * 3 + 1).to(dtype)
+    want = O.standardize(x, ex, 1e-6)
+    out = _standardize(x.to("cuda:0"), ex, eps=1e-6)
+    torch.testing.assert_close(out.cpu(), want, equal_nan=True, **tol(dtype))
+    # the device statistics are reproducible run to run (fixed reduction order)
+    assert torch.equal(out, _standardize(x.to("cuda:0"), ex, eps=1e-6)) or torch.isnan(out).any()

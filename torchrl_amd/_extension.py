@@ -53,6 +53,9 @@ _PROTOTYPES = {
                               _i64, _i64, _i64, _vp, _vp, _vp, _sz, _int]),
     "trl_normalize": (_int, [_vp, _int, _vp, _i64, _vp, _dbl, _vp]),
     "trl_moments": (_int, [_vp, _int, _vp, _i64, _vp, _vp, _sz]),
+    "trl_grouped_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "trl_moments_grouped": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp, _vp, _sz]),
+    "trl_normalize_grouped": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp, _dbl, _vp]),
     "trl_xchg_handle_bytes": (_sz, []),
     "trl_xchg_local_init": (_int, [ctypes.POINTER(_vp), _vp]),
     "trl_xchg_open": (_int, [_vp, _vp, ctypes.POINTER(_int), _int, _int, _dbl, ctypes.POINTER(_vp)]),

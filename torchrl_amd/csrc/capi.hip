@@ -248,6 +248,38 @@ int trl_normalize(void *stream, int dtype, const void *x, int64_t n, const doubl
     return TRL_OK;
 }
 
+size_t trl_grouped_workspace_bytes(int64_t outer, int64_t G, int64_t inner) {
+    if (outer <= 0 || G <= 0 || inner <= 0) return 0;
+    return (size_t)G * (size_t)grouped_blocks_per_group(outer, G, inner) * 2 * sizeof(double) + 256;
+}
+
+int trl_moments_grouped(void *stream, int dtype, const void *x, int64_t outer, int64_t G, int64_t inner, double *stats,
+                        void *workspace, size_t workspace_bytes) {
+    if (!dtype_ok(dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_moments_grouped: bad dtype");
+    if (int rc = check_dims("trl_moments_grouped", outer, G, inner)) return rc;
+    if (!x || !stats) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_moments_grouped: null pointer");
+    if (G > 65535) return fail(TRL_ERR_UNSUPPORTED, "trl_moments_grouped: at most 65535 groups (got %lld)", (long long)G);
+    if (!workspace || workspace_bytes < trl_grouped_workspace_bytes(outer, G, inner) || ((uintptr_t)workspace & 7))
+        return fail(TRL_ERR_WORKSPACE, "trl_moments_grouped: workspace is %zu bytes, need %zu (8-byte aligned)", workspace_bytes,
+                    trl_grouped_workspace_bytes(outer, G, inner));
+    launch_moments_grouped((hipStream_t)stream, dtype, x, outer, G, inner, (double *)workspace, stats);
+    if (int rc = check_launch("trl_moments_grouped")) return rc;
+    g_kernel = "moments_grouped";
+    return TRL_OK;
+}
+
+int trl_normalize_grouped(void *stream, int dtype, const void *x, int64_t outer, int64_t G, int64_t inner, const double *stats,
+                          double eps, void *out) {
+    if (!dtype_ok(dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_normalize_grouped: bad dtype");
+    if (int rc = check_dims("trl_normalize_grouped", outer, G, inner)) return rc;
+    if (!x || !stats || !out) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_normalize_grouped: null pointer");
+    if (G > 65535) return fail(TRL_ERR_UNSUPPORTED, "trl_normalize_grouped: at most 65535 groups (got %lld)", (long long)G);
+    launch_normalize_grouped((hipStream_t)stream, dtype, x, outer, G, inner, stats, eps, out);
+    if (int rc = check_launch("trl_normalize_grouped")) return rc;
+    g_kernel = "normalize_grouped";
+    return TRL_OK;
+}
+
 int trl_moments(void *stream, int dtype, const void *x, int64_t n, double *stats, void *workspace, size_t workspace_bytes) {
     if (!dtype_ok(dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_moments: bad dtype");
     if (n <= 0 || !x || !stats) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_moments: null pointer or n <= 0");

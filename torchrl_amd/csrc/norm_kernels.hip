@@ -121,6 +121,95 @@ __global__ __launch_bounds__(kRedThreads) void normalize_from_partials_kernel(co
     }
 }
 
+// ---- grouped statistics: `_standardize(x, exclude_dims)` (reference: torchrl/_utils.py:875-936) ---------
+// The excluded dims index G independent groups; x is seen as (outer, G, inner) contiguous, element
+// f = (o*G + g)*inner + j belongs to group g (the host merges / permutes dims into this pattern).
+// Statistics per group: {M, sum, sumsq} in fp64, fixed order, M = outer*inner.
+template <typename TS>
+__global__ __launch_bounds__(kRedThreads) void moments_grouped_kernel(const TS *__restrict__ x, i64 outer, i64 G, i64 inner,
+                                                                      double *__restrict__ partials) {
+    __shared__ double red[2 * kRedThreads / kWave];
+    const i64 g = blockIdx.y;
+    const i64 M = outer * inner;
+    double s = 0.0, ss = 0.0;
+    const i64 stride = (i64)gridDim.x * kRedThreads;
+    if (inner == 1) {
+        for (i64 m = (i64)blockIdx.x * kRedThreads + threadIdx.x; m < M; m += stride) {
+            const double xv = (double)x[m * G + g];
+            s += xv;
+            ss += xv * xv;
+        }
+    } else {
+        for (i64 m = (i64)blockIdx.x * kRedThreads + threadIdx.x; m < M; m += stride) {
+            const i64 o = m / inner, j = m - o * inner;
+            const double xv = (double)x[(o * G + g) * inner + j];
+            s += xv;
+            ss += xv * xv;
+        }
+    }
+    block_sum2<kRedThreads>(s, ss, red);
+    if (threadIdx.x == 0) {
+        partials[2 * (g * gridDim.x + blockIdx.x)] = s;
+        partials[2 * (g * gridDim.x + blockIdx.x) + 1] = ss;
+    }
+}
+
+__global__ __launch_bounds__(kRedThreads) void reduce_partials_grouped_kernel(const double *__restrict__ partials, int nper,
+                                                                              double m_count, double *__restrict__ stats) {
+    __shared__ double red[2 * kRedThreads / kWave];
+    const i64 g = blockIdx.x;
+    double s = 0.0, ss = 0.0;
+    for (int k = threadIdx.x; k < nper; k += kRedThreads) {
+        s += partials[2 * (g * nper + k)];
+        ss += partials[2 * (g * nper + k) + 1];
+    }
+    block_sum2<kRedThreads>(s, ss, red);
+    if (threadIdx.x == 0) {
+        stats[3 * g] = m_count;
+        stats[3 * g + 1] = s;
+        stats[3 * g + 2] = ss;
+    }
+}
+
+constexpr int kMaxTableGroups = 2048;  // (mean, std) table in LDS: 2048 * 2 * 8 B = 32 KiB
+
+// Flat, coalesced scale pass; every block first derives the per-group (mean, std) table into LDS.
+template <typename TS>
+__global__ __launch_bounds__(kRedThreads) void normalize_grouped_kernel(const TS *__restrict__ x, i64 n, i64 G, i64 inner,
+                                                                        const double *__restrict__ stats, double eps,
+                                                                        TS *__restrict__ out) {
+    __shared__ TS tab[2 * kMaxTableGroups];
+    for (i64 g = threadIdx.x; g < G; g += kRedThreads) {
+        TS mean_s, std_s;
+        mean_std<TS>(stats[3 * g], stats[3 * g + 1], stats[3 * g + 2], eps, mean_s, std_s);
+        tab[2 * g] = mean_s;
+        tab[2 * g + 1] = std_s;
+    }
+    __syncthreads();
+    const i64 stride = (i64)gridDim.x * kRedThreads;
+    for (i64 f = (i64)blockIdx.x * kRedThreads + threadIdx.x; f < n; f += stride) {
+        const i64 g = (f / inner) % G;
+        out[f] = (x[f] - tab[2 * g]) / tab[2 * g + 1];
+    }
+}
+
+// Many groups (G > kMaxTableGroups): one block column per group, as the moments kernel walks them.
+template <typename TS>
+__global__ __launch_bounds__(kRedThreads) void normalize_grouped_by_group_kernel(const TS *__restrict__ x, i64 outer, i64 G, i64 inner,
+                                                                                 const double *__restrict__ stats, double eps,
+                                                                                 TS *__restrict__ out) {
+    const i64 g = blockIdx.y;
+    const i64 M = outer * inner;
+    TS mean_s, std_s;
+    mean_std<TS>(stats[3 * g], stats[3 * g + 1], stats[3 * g + 2], eps, mean_s, std_s);
+    const i64 stride = (i64)gridDim.x * kRedThreads;
+    for (i64 m = (i64)blockIdx.x * kRedThreads + threadIdx.x; m < M; m += stride) {
+        const i64 o = m / inner, j = m - o * inner;
+        const i64 f = (o * G + g) * inner + j;
+        out[f] = (x[f] - mean_s) / std_s;
+    }
+}
+
 inline i64 stream_blocks(i64 n, int per_thread) {
     i64 nb = (n + (i64)kRedThreads * per_thread - 1) / ((i64)kRedThreads * per_thread);
     if (nb < 1) nb = 1;
@@ -168,5 +257,52 @@ int launch_normalize(hipStream_t s, int dt, const void *x, i64 n, const double *
         hipLaunchKernelGGL((normalize_kernel<float>), dim3((unsigned)nb), dim3(kRedThreads), 0, s, (const float *)x, n, stats, eps, (float *)out, vec_ok);
     else
         hipLaunchKernelGGL((normalize_kernel<double>), dim3((unsigned)nb), dim3(kRedThreads), 0, s, (const double *)x, n, stats, eps, (double *)out, vec_ok);
+    return 0;
+}
+
+// ---- grouped -----------------------------------------------------------------------------------
+i64 grouped_blocks_per_group(i64 outer, i64 G, i64 inner) {
+    const i64 M = outer * inner;
+    i64 nb = (M + (i64)kRedThreads * 4 - 1) / ((i64)kRedThreads * 4);
+    const i64 cap = 4096 / G > 1 ? 4096 / G : 1;  // ~4096 blocks in total
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    return nb;
+}
+
+int launch_moments_grouped(hipStream_t s, int dt, const void *x, i64 outer, i64 G, i64 inner, double *partials, double *stats) {
+    if (G > 65535) return 2;
+    const i64 nb = grouped_blocks_per_group(outer, G, inner);
+    const dim3 grid((unsigned)nb, (unsigned)G);
+    if (dt == 0)
+        hipLaunchKernelGGL((moments_grouped_kernel<float>), grid, dim3(kRedThreads), 0, s, (const float *)x, outer, G, inner, partials);
+    else
+        hipLaunchKernelGGL((moments_grouped_kernel<double>), grid, dim3(kRedThreads), 0, s, (const double *)x, outer, G, inner, partials);
+    hipLaunchKernelGGL(reduce_partials_grouped_kernel, dim3((unsigned)G), dim3(kRedThreads), 0, s, partials, (int)nb,
+                       (double)outer * (double)inner, stats);
+    return 0;
+}
+
+int launch_normalize_grouped(hipStream_t s, int dt, const void *x, i64 outer, i64 G, i64 inner, const double *stats, double eps,
+                             void *out) {
+    if (G > 65535) return 2;
+    const i64 n = outer * G * inner;
+    if (G <= kMaxTableGroups) {
+        const i64 nb = stream_blocks(n, 4);
+        if (dt == 0)
+            hipLaunchKernelGGL((normalize_grouped_kernel<float>), dim3((unsigned)nb), dim3(kRedThreads), 0, s, (const float *)x, n, G,
+                               inner, stats, eps, (float *)out);
+        else
+            hipLaunchKernelGGL((normalize_grouped_kernel<double>), dim3((unsigned)nb), dim3(kRedThreads), 0, s, (const double *)x, n, G,
+                               inner, stats, eps, (double *)out);
+    } else {
+        const dim3 grid((unsigned)grouped_blocks_per_group(outer, G, inner), (unsigned)G);
+        if (dt == 0)
+            hipLaunchKernelGGL((normalize_grouped_by_group_kernel<float>), grid, dim3(kRedThreads), 0, s, (const float *)x, outer, G,
+                               inner, stats, eps, (float *)out);
+        else
+            hipLaunchKernelGGL((normalize_grouped_by_group_kernel<double>), grid, dim3(kRedThreads), 0, s, (const double *)x, outer, G,
+                               inner, stats, eps, (double *)out);
+    }
     return 0;
 }
