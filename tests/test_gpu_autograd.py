@@ -106,8 +106,54 @@ def test_module_diff_reward():
     assert data2.get("advantage").is_leaf and not data2.get("advantage").requires_grad
 
 
-def test_vtrace_grad_raises_loudly():
-    r = torch.randn(3, 8, 1, device=DEV, requires_grad=True)
+def torch_vtrace(gamma, lp, lm, v, nv, r, done, term, rho_th, c_th):
+    """functional.py:1316-1350 restated with differentiable torch ops."""
+    nd, nt = (~done).to(v.dtype), (~term).to(v.dtype)
+    rho = (lp - lm).exp()
+    rb, cb = rho.clamp_max(rho_th), rho.clamp_max(c_th)
+    delta = rb * (r + gamma * nt * nv - v)
+    x = torch.zeros_like(v[:, 0])
+    xs = []
+    for t in reversed(range(v.shape[1])):
+        g = gamma[:, t] if torch.is_tensor(gamma) and gamma.ndim else gamma
+        x = delta[:, t] + (g * nd[:, t]) * cb[:, t] * x
+        xs.append(x)
+    vs = torch.stack(xs[::-1], 1) + v
+    vsp = torch.cat([vs[:, 1:], nv[:, -1:]], 1)
+    return rb * (r + gamma * nt * vsp - v), vs
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", [(16, 32, 1), (3, 2500, 1), (5, 20, 3)], ids=["16x32", "3x2500", "5x20x3"])
+@pytest.mark.parametrize("tensor_gamma", [False, True], ids=["g_scalar", "g_tensor"])
+def test_vtrace_gradients(shape, dtype, tensor_gamma):
+    """Gradients to state_value / next_state_value / reward / log_pi / log_mu, thresholds that clip
+    about half of the ratios (the clipped branch has zero gradient, as clamp_max's)."""
+    v, nv, r, done, term, gam, wa, wv = _inputs(shape, dtype)
+    g = torch.Generator().manual_seed(5)
+    lp = (0.5 * torch.randn(shape, generator=g, dtype=torch.float64)).to(dtype).to(DEV).requires_grad_(True)
+    lm = (0.5 * torch.randn(shape, generator=g, dtype=torch.float64)).to(dtype).to(DEV).requires_grad_(True)
+    gamma = gam if tensor_gamma else 0.97
+    g32 = gamma if tensor_gamma else float(torch.tensor(0.97, dtype=torch.float32))  # python gamma rounds to the default dtype
+    adv, vs = F.vtrace_advantage_estimate(gamma, lp, lm, v, nv, r, done, term, rho_thresh=1.0, c_thresh=0.9)
+    assert adv.requires_grad and vs.requires_grad
+    loss = (adv * wa).sum() + (vs * wv).sum()
+    grads = torch.autograd.grad(loss, (lp, lm, v, nv, r))
+    d = lambda x: x.detach().double().requires_grad_(True)
+    ins = [d(t) for t in (lp, lm, v, nv, r)]
+    gd = gamma.double() if tensor_gamma else g32
+    adv2, vs2 = torch_vtrace(gd, ins[0], ins[1], ins[2], ins[3], ins[4], done, term, 1.0, float(torch.tensor(0.9, dtype=torch.float32)))
+    loss2 = (adv2 * wa.double()).sum() + (vs2 * wv.double()).sum()
+    want = torch.autograd.grad(loss2, ins)
+    tol = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=1e-9, atol=1e-9)
+    for name, got, w in zip(("log_pi", "log_mu", "state_value", "next_state_value", "reward"), grads, want):
+        assert got.dtype == dtype and got.shape == w.shape
+        torch.testing.assert_close(got.double(), w, msg=lambda m, n=name: f"{n}: {m}", **tol)
+
+
+def test_vtrace_grad_to_gamma_raises_loudly():
+    r = torch.randn(3, 8, 1, device=DEV)
+    gam = torch.full((3, 8, 1), 0.9, device=DEV, requires_grad=True)
     d = torch.zeros(3, 8, 1, dtype=torch.bool, device=DEV)
-    with pytest.raises(NotImplementedError, match="not implemented yet"):
-        F.vtrace_advantage_estimate(0.9, r, r, r, r, r, d)
+    with pytest.raises(NotImplementedError, match="gamma"):
+        F.vtrace_advantage_estimate(gam, r, r, r, r, r, d)

@@ -70,6 +70,11 @@ def main():
     call = F._prepare_gae(0.9, 0.9, v, nv, r, d, t, -3)
     st = F.prepare_gae_step(call, normalize=False)
     report("C3 [4096x100x5] GAE f32 (kernel only)", timeit(st.run, it), n, 22)
+    # PPO-side _standardize on the C3 advantage, agent dim kept independent (two passes: 4 + 4 B read, 4 B written)
+    from torchrl_amd._utils import _standardize
+    adv = st.run()[0].view(shape)
+    report("C3 [4096x100x5] _standardize(exclude agent dim) f32", timeit(lambda: _standardize(adv, (-2,)), it), n, 12)
+    report("C3 [4096x100x5] _standardize(all dims) f32", timeit(lambda: _standardize(adv, ()), it), n, 12)
     # C4
     shape = (65536, 32, 1)
     r, v, nv, d, t, gam, lp, lm = inputs(shape, f32, 0.01)

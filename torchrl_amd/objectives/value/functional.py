@@ -237,7 +237,7 @@ def _needs_grad(*xs) -> bool:
 
 
 _GRAD_MSG = (
-    "torchrl_amd: differentiating through {} is not implemented yet (GAE and TD(lambda) are); "
+    "torchrl_amd: differentiating through {} is not implemented yet (GAE, TD(lambda) and V-trace are); "
     "call it under torch.no_grad() / with differentiable=False, or detach the inputs."
 )
 
@@ -392,7 +392,7 @@ def _launch_gae_normalize(c: _GaeCall, eps: float, algo: int = ALGO_AUTO, out=No
 # "terminated", which makes delta = gbar' exactly) on flipped inputs with the masks shifted by one
 # step.  Gradients flow to reward / state_value / next_state_value (reference behaviour under
 # differentiable=True, test/test_cost.py:15521-15584); gamma / lmbda tensors that require grad are
-# not supported.  V-trace has no backward here yet.
+# not supported.  V-trace: _VtraceFunction below (also to log_pi / log_mu).
 def _adjoint_scan(gbar3: torch.Tensor, done3: torch.Tensor, lg3: Optional[torch.Tensor], lg: float, cdt) -> torch.Tensor:
     """G (O,T,I) from gbar (O,T,I): G_t = gbar_t + (lg_{t-1} * (1-done_{t-1})) * G_{t-1}."""
     O, T, I = gbar3.shape
@@ -473,6 +473,65 @@ class _TdLambdaFunction(torch.autograd.Function):
         d_nv = d_nvm * (1 - c.terminated.view(shp3)).to(dt)
         outs = (d_nv, G)
         return tuple(o.to(d).view(s) for o, d, s in zip(outs, ctx.in_dtypes, ctx.in_shapes)) + (None, None)
+
+
+class _VtraceFunction(torch.autograd.Function):
+    """V-trace with gradients to state_value / next_state_value / reward / log_pi / log_mu.  Forward on
+    trl_vtrace_fwd; backward = elementwise torch ops + ONE adjoint scan on the HIP scan kernels."""
+
+    @staticmethod
+    def forward(ctx, log_pi, log_mu, state_value, next_state_value, reward, call):
+        adv, vs = _launch_vtrace(call)
+        ctx.call = call
+        ctx.ins = tuple((t.dtype, t.shape) for t in (log_pi, log_mu, state_value, next_state_value, reward))
+        ctx.save_for_backward(vs)
+        return adv, vs
+
+    @staticmethod
+    def backward(ctx, g_adv, g_vs):
+        c = ctx.call
+        (vs,) = ctx.saved_tensors
+        shp3 = (c.O, c.T, c.I)
+        dt = torch.promote_types(c.vdt, c.cdt)
+        dev = c.reward.device
+        z = lambda g: torch.zeros(shp3, dtype=dt, device=dev) if g is None else g.to(dt).contiguous().view(shp3)
+        A, S = z(g_adv), z(g_vs)
+        v3 = lambda t: t.view(shp3).to(dt)
+        lp, lm, v, nv, r = v3(c.log_pi), v3(c.log_mu), v3(c.value), v3(c.next_value), v3(c.reward)
+        vs3 = vs.view(shp3).to(dt)
+        nd, nt = (1 - c.done.view(shp3)).to(dt), (1 - c.terminated.view(shp3)).to(dt)
+        gam = v3(c.gamma_t) if c.gamma_t is not None else torch.full((), c.gamma, dtype=dt, device=dev)
+        rho = (lp - lm).exp()
+        rb, cb = rho.clamp_max(c.rho_thresh), rho.clamp_max(c.c_thresh)
+        g_nt, g_nd = gam * nt, gam * nd
+        vsp = torch.cat([vs3[:, 1:], nv[:, -1:]], 1)          # functional.py:1343-1345: the shift ignores done
+        d_rb = A * (r + g_nt * vsp - v)
+        d_vsp = A * rb * g_nt
+        s_tot = S + torch.cat([torch.zeros_like(d_vsp[:, :1]), d_vsp[:, :-1]], 1)
+        a = (g_nd * cb).expand(shp3).contiguous()              # x_t = delta_t + a_t x_{t+1}
+        X = _adjoint_scan(s_tot, torch.zeros(shp3, dtype=torch.bool, device=dev).view(torch.uint8), a, 0.0, dt)
+        x_next = torch.cat([(vs3 - v)[:, 1:], torch.zeros_like(v[:, :1])], 1)
+        d_rb = d_rb + X * (r + g_nt * nv - v)
+        d_cb = X * x_next * g_nd
+        d_rho = d_rb * (rho <= c.rho_thresh).to(dt) + d_cb * (rho <= c.c_thresh).to(dt)
+        d_lp = d_rho * rho
+        w = (A + X) * rb
+        d_nv = X * rb * g_nt
+        d_nv = torch.cat([d_nv[:, :-1], d_nv[:, -1:] + d_vsp[:, -1:]], 1)
+        outs = (d_lp, -d_lp, s_tot - w, d_nv, w)
+        def back(o, d, sh):
+            o = o.reshape(c.shape)
+            if tuple(sh) != tuple(c.shape):  # a broadcast log-prob: sum the gradient over the expanded dims
+                while len(sh) < o.dim():
+                    sh = tuple(sh) + (1,)
+                o = o.sum_to_size(sh).reshape(ctx.ins[0][1] if False else sh)
+            return o.to(d)
+
+        res = []
+        for o, (d, sh) in zip(outs, ctx.ins):
+            g = back(o, d, tuple(sh))
+            res.append(g.reshape(sh) if g.numel() == math.prod(sh) else g)
+        return tuple(res) + (None,)
 
 
 def _no_coef_grad(name, *coefs):
@@ -987,10 +1046,11 @@ def vtrace_advantage_estimate(
 
     Returns ``(advantages, vs)``.  ``terminated=None`` makes ``not_terminated = not_done``.
     """
-    if _needs_grad(log_pi, log_mu, state_value, next_state_value, reward, gamma):
-        raise NotImplementedError(_GRAD_MSG.format("vtrace_advantage_estimate"))
     call = _prepare_vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward, done, terminated,
                            rho_thresh, c_thresh, time_dim)
+    if _needs_grad(log_pi, log_mu, state_value, next_state_value, reward, gamma):
+        _no_coef_grad("vtrace_advantage_estimate", gamma)
+        return _VtraceFunction.apply(log_pi, log_mu, state_value, next_state_value, reward, call)
     return _launch_vtrace(call)
 
 
