@@ -50,7 +50,7 @@ def _worker(rank, world, port, q):
         r, v, nv, done, term = _inputs()
         lo, hi = rank * 32, (rank + 1) * 32  # env dimension sharded
         adv, vt = F.gae_normalized(0.99, 0.95, v[lo:hi], nv[lo:hi], r[lo:hi], done[lo:hi], term[lo:hi], eps=1e-4, distributed=True)
-        q.put((rank, adv, vt))
+        q.put((rank, adv.numpy(), vt.numpy()))  # plain arrays: no fd passing that would race with the worker's exit
     finally:
         dist.destroy_process_group()
 
@@ -68,7 +68,7 @@ def test_sharded_normalisation_equals_single_process():
     got = dict()
     for _ in range(world):
         rk, adv, vt = q.get(timeout=90)
-        got[rk] = (adv, vt)
+        got[rk] = (torch.from_numpy(adv), torch.from_numpy(vt))
     for p in procs:
         p.join(30)
         assert p.exitcode == 0

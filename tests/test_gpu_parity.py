@@ -355,3 +355,19 @@ def test_lookback_undiscounted_carry_crosses_every_chunk():
     oret = O.td_lambda(1.0, 1.0, nv, r, done, done)
     tcall = F._prepare_td_lambda(1.0, 1.0, cu(nv), cu(r), cu(done), cu(done), None, -2)
     torch.testing.assert_close(F._launch_td_lambda(tcall, torch.float64, algo=SCAN).cpu(), oret, rtol=1e-11, atol=1e-9)
+
+
+def test_entry_points_inside_a_compiled_region():
+    """torch.compile (dynamo, eager backend: no code generator needed): the estimators are opaque
+    calls inside a compiled function and give the eager result."""
+    r, v, nv, done, term, gam, lp, lm = (cu(t) for t in _rand_inputs((32, 64, 1), torch.float32, seed=2))
+
+    def fn(v, nv, r):
+        adv, vt = F.generalized_advantage_estimate(0.99, 0.95, v * 1.0, nv, r, done, term)
+        ret = F.td_lambda_return_estimate(0.99, 0.95, nv, r, done, term)
+        return adv * 2.0 + vt, ret + 1.0
+
+    want = fn(v, nv, r)
+    got = torch.compile(fn, backend="eager")(v, nv, r)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)

@@ -1181,3 +1181,20 @@ def reward2go(reward, done, gamma, *, time_dim: int = -2):
     call = _prepare_gae(1.0, g, zeros, zeros, reward, done, torch.ones_like(done, dtype=torch.bool), time_dim)
     adv, _, _ = _launch_gae(call)
     return adv
+
+
+# ---------------------------------------------------------------------------------------------
+# torch.compile: every entry point is one native launch behind ctypes -- there is nothing for a
+# tracing compiler to fuse, and dynamo cannot look through ctypes.  The entry points are marked
+# opaque, so a compiled region that calls them runs them eagerly between its own graphs (the
+# reference instead flips its estimators to the Python loop under dynamo, advantages.py:1303-1307).
+# ---------------------------------------------------------------------------------------------
+_OPAQUE = (
+    "generalized_advantage_estimate", "vec_generalized_advantage_estimate", "gae_with_stats", "gae_normalized",
+    "td_lambda_return_estimate", "vec_td_lambda_return_estimate", "td_lambda_advantage_estimate",
+    "vec_td_lambda_advantage_estimate", "vtrace_advantage_estimate", "td1_return_estimate", "vec_td1_return_estimate",
+    "td1_advantage_estimate", "vec_td1_advantage_estimate", "reward2go", "moments", "normalize_", "standardize",
+)
+for _name in _OPAQUE:
+    globals()[_name] = torch.compiler.disable(globals()[_name], recursive=True)
+del _name
