@@ -478,8 +478,8 @@ Plan make_plan(i64 O, i64 T, i64 I, int V, bool ptr_align_ok, int cus, size_t lb
         p.rows_per_chunk = (int)R;
         p.nchunks = (O + R - 1) / R;
         i64 nb = p.nchunks;
-        if (nb > (i64)cus * 4) nb = (i64)cus * 4;
-        if (nb > 4096) nb = 4096;  // ~4 resident teams per CU, chunks walked grid-stride
+        if (nb > (i64)cus * 8) nb = (i64)cus * 8;
+        if (nb > 4096) nb = 4096;  // up to 8 resident teams per CU (15.0 vs 16.8 us at C3 with 4), chunks walked grid-stride
         p.nblocks = nb;
         p.vec = ptr_align_ok && (p.nchunks == 1 || (R * T * I) % V == 0);
         p.wave_indep = ((i64)kWave * V) % T == 0;
