@@ -371,3 +371,17 @@ def test_entry_points_inside_a_compiled_region():
     got = torch.compile(fn, backend="eager")(v, nv, r)
     for a, b in zip(got, want):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(0, 8, 1), (4, 0, 1), (3, 5, 0)], ids=["no_rows", "no_steps", "no_features"])
+def test_empty_inputs_give_empty_outputs(shape):
+    """The reference's loops run zero steps on empty tensors and return empty tensors of the input shape."""
+    z = torch.zeros(shape, device=DEV)
+    d = torch.zeros(shape, dtype=torch.bool, device=DEV)
+    adv, vt = F.generalized_advantage_estimate(0.9, 0.9, z, z, z, d, d)
+    assert adv.shape == vt.shape == torch.Size(shape) and adv.dtype == torch.float32
+    assert F.td_lambda_return_estimate(0.9, 0.9, z, z, d, d).shape == torch.Size(shape)
+    va, vs = F.vtrace_advantage_estimate(0.9, z, z, z, z, z, d, d)
+    assert va.shape == vs.shape == torch.Size(shape)
+    adv, vt = F.gae_normalized(0.9, 0.9, z, z, z, d, d)
+    assert adv.shape == torch.Size(shape)

@@ -341,6 +341,9 @@ def _launch_gae(c: _GaeCall, want_stats: bool = False, algo: int = ALGO_AUTO, ou
     adv, vt = out if out is not None else (torch.empty(c.shape, dtype=c.vdt, device=dev), torch.empty(c.shape, dtype=c.vdt, device=dev))
     stats = ws = None
     ws_bytes = 0
+    if c.O * c.T * c.I == 0:  # nothing to scan (the reference's loop runs zero steps): empty outputs, zero moments
+        stats = torch.zeros(3, dtype=torch.float64, device=dev) if want_stats else None
+        return adv.to(c.out_dtype), vt.to(c.out_dtype), stats
     if want_stats:
         ws = _workspace(lib, dev, c.O, c.T, c.I)
         stats = torch.empty(3, dtype=torch.float64, device=dev)
@@ -366,6 +369,10 @@ def _launch_gae_normalize(c: _GaeCall, eps: float, algo: int = ALGO_AUTO, out=No
     _require_hip(c.next_value)
     dev = c.next_value.device
     adv, vt = out if out is not None else (torch.empty(c.shape, dtype=c.vdt, device=dev), torch.empty(c.shape, dtype=c.vdt, device=dev))
+    if c.O * c.T * c.I == 0:
+        if exchange is not None:
+            raise NotImplementedError("gae_normalized: an empty shard cannot take part in the cross-GPU exchange")
+        return adv.to(c.out_dtype), vt.to(c.out_dtype), (torch.zeros(3, dtype=torch.float64, device=dev) if want_stats else None)
     ws = _workspace(lib, dev, c.O, c.T, c.I)
     stats = torch.empty(3, dtype=torch.float64, device=dev) if want_stats else None
     head = (_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.value), _ptr(c.next_value),
@@ -820,6 +827,8 @@ def _launch_td_lambda(c: _TdLambdaCall, out_dtype, algo: int = ALGO_AUTO) -> tor
     _require_hip(c.next_value)
     dev = c.next_value.device
     out = torch.empty(c.shape, dtype=c.vdt, device=dev)
+    if c.O * c.T * c.I == 0:
+        return out.to(out_dtype)
     ws = _lookback_workspace(lib, dev, c.O, c.T, c.I) if c.rolling else None
     with torch.cuda.device(dev):
         rc = lib.trl_td_lambda_fwd(
@@ -1018,6 +1027,8 @@ def _launch_vtrace(c: _VtraceCall, algo: int = ALGO_AUTO):
     odt = torch.promote_types(c.vdt, c.cdt)
     adv = torch.empty(c.shape, dtype=odt, device=dev)
     vs = torch.empty(c.shape, dtype=odt, device=dev)
+    if c.O * c.T * c.I == 0:
+        return adv, vs
     ws = _lookback_workspace(lib, dev, c.O, c.T, c.I)
     with torch.cuda.device(dev):
         rc = lib.trl_vtrace_fwd(
