@@ -121,8 +121,11 @@ __global__ __launch_bounds__(kShortThreads) void scan_short_kernel(typename Op::
 // then looks exactly like RO*I time-contiguous rows of length T and goes through the same
 // scan_chunk.  Outputs take the inverse route (LDS scatter, coalesced 16-byte stores), so HBM
 // traffic stays at the algorithmic bytes.
+#ifndef IL_WAVES
+#define IL_WAVES 4
+#endif
 template <class Op, bool VEC, bool WAVE_INDEP>
-__global__ __launch_bounds__(kTeam) void scan_interleaved_kernel(typename Op::Args args, ScanGeom geo, int I, double *partials) {
+__global__ __launch_bounds__(kTeam, IL_WAVES) void scan_interleaved_kernel(typename Op::Args args, ScanGeom geo, int I, double *partials) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
     typedef typename Op::TO TO;
@@ -160,22 +163,17 @@ __global__ __launch_bounds__(kTeam) void scan_interleaved_kernel(typename Op::Ar
     };
 
     double s = 0.0, ss = 0.0;
-    typename Op::Raw cur, nxt;
     i64 start;
     int count;
+    // No register prefetch here: the kernel is occupancy-bound (VGPRs), and with up to 8 teams per
+    // CU in flight the other teams' loads cover this team's latency.
     const i64 niter = (geo.nchunks + gridDim.x - 1) / gridDim.x;
-    geom_of(blockIdx.x, start, count);
-    load_inputs<Op, VEC>(args, start + lane_off, clamp_nvalid(count, lane_off, V), cur);
     for (i64 it = 0; it < niter; ++it) {
         const i64 c = it * gridDim.x + blockIdx.x;
-        if (it + 1 < niter) {
-            i64 nstart;
-            int ncount;
-            geom_of(c + gridDim.x, nstart, ncount);
-            load_inputs<Op, VEC>(args, nstart + lane_off, clamp_nvalid(ncount, lane_off, V), nxt);
-        }
         geom_of(c, start, count);
         const int nvalid = clamp_nvalid(count, lane_off, V);
+        typename Op::Raw cur;
+        load_inputs<Op, VEC>(args, start + lane_off, nvalid, cur);
         // stage the chunk in LDS in memory order, then gather this lane's (o,i)-row elements
         {
             size_t off = 0;
@@ -229,7 +227,6 @@ __global__ __launch_bounds__(kTeam) void scan_interleaved_kernel(typename Op::Ar
             }
             store_outputs<Op, VEC>(args, start + lane_off, nvalid, o0, o1);
         }
-        cur = nxt;
     }
     if (partials) {
         block_sum2<kTeam>(s, ss, red);
