@@ -376,7 +376,8 @@ __global__ __launch_bounds__(kLongThreads) void scan_lookback_kernel(typename Op
             store_outputs<Op, VEC>(args, flat, nvalid, o0, o1);
         },
         [&](TeamShared<Op> &shm, int buf, TC &xc, TS &xv) {
-            if (threadIdx.x == 0) {
+            if (threadIdx.x < kWave) {  // wave 0 resolves the carry: 64 records per look-back round
+                const int lane = threadIdx.x;
                 // this chunk's aggregate: x_first = G0(G1(G2(G3(x_in))))
                 Aff<TC> agg{shm.a[buf][kWaves - 1], shm.b[buf][kWaves - 1], shm.h[buf][kWaves - 1]};
 #pragma unroll
@@ -387,45 +388,67 @@ __global__ __launch_bounds__(kLongThreads) void scan_lookback_kernel(typename Op
                 bool ok = true;
                 if (agg.h) {
                     // the chunk holds its row's end: inclusive value known at once
-                    lb_store(&myrec->x, lb_bits(agg.b));
-                    lb_store(&myrec->v0, lb_bits(my_v0));
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    lb_store(&myrec->flag, 2ull);
+                    if (lane == 0) {
+                        lb_store(&myrec->x, lb_bits(agg.b));
+                        lb_store(&myrec->v0, lb_bits(my_v0));
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        lb_store(&myrec->flag, 2ull);
+                    }
                 } else {
-                    lb_store(&myrec->a, lb_bits(agg.a));
-                    lb_store(&myrec->b, lb_bits(agg.b));
-                    lb_store(&myrec->v0, lb_bits(my_v0));
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    lb_store(&myrec->flag, 1ull);
-                    // look back: compose the aggregates of the following chunks until an inclusive value
+                    if (lane == 0) {
+                        lb_store(&myrec->a, lb_bits(agg.a));
+                        lb_store(&myrec->b, lb_bits(agg.b));
+                        lb_store(&myrec->v0, lb_bits(my_v0));
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        lb_store(&myrec->flag, 1ull);
+                    }
+                    // look back: lane l reads the record of chunk base + l; the records up to the first inclusive
+                    // one are composed in chunk order by a wave reduction; no inclusive among the 64 -> next 64
                     Aff<TC> acc{(TC)1, (TC)0, 0};
                     const unsigned long long t_start = wall_clock64();
-                    for (int cur = c + 1;; ++cur) {
-                        const LbRecord *r = rec + row * nchunks + cur;
-                        unsigned long long f;
-                        while ((f = lb_load(&r->flag)) == 0ull) {
+                    for (int base = c + 1; ok; base += kWave) {
+                        const int idx = base + lane;
+                        const bool valid = idx < nchunks;
+                        const LbRecord *r = rec + row * nchunks + (valid ? idx : nchunks - 1);
+                        unsigned long long f = 0ull;
+                        int first = kWave;
+                        for (;;) {
+                            if (valid && f == 0ull) f = lb_load(&r->flag);  // only the records still missing are re-polled
+                            const unsigned long long incl = __ballot(valid && f == 2ull);
+                            first = incl ? (int)__ffsll((long long)incl) - 1 : kWave;
+                            if (__all(!(valid && lane <= first) || f != 0ull)) break;
                             if (wall_clock64() - t_start > 100000000ull) { ok = false; break; }
                             __builtin_amdgcn_s_sleep(1);
                         }
                         if (!ok) break;
-                        if (cur == c + 1) carry_v = lb_val<TS>(lb_load(&r->v0));
-                        if (f == 2ull) {
-                            carry = apply(acc, lb_val<TC>(lb_load(&r->x)));
-                            break;
+                        if (first == kWave && !__all(valid)) { ok = false; break; }  // ran past the row's end: cannot happen
+                        Aff<TC> el{(TC)1, (TC)0, 0};
+                        if (valid && lane < first) el = Aff<TC>{lb_val<TC>(lb_load(&r->a)), lb_val<TC>(lb_load(&r->b)), 0};
+                        else if (valid && lane == first) el = Aff<TC>{(TC)0, lb_val<TC>(lb_load(&r->x)), 1};  // constant map
+                        if (base == c + 1 && lane == 0) carry_v = lb_val<TS>(lb_load(&r->v0));
+#pragma unroll
+                        for (int off = 1; off < kWave; off <<= 1) {
+                            const Aff<TC> p = shfl_down_aff(el, off);
+                            if (lane + off < kWave) el = compose(el, p);
                         }
-                        const TC ra = lb_val<TC>(lb_load(&r->a)), rb = lb_val<TC>(lb_load(&r->b));
-                        acc = compose(acc, Aff<TC>{ra, rb, 0});
+                        acc = compose(acc, Aff<TC>{__shfl(el.a, 0, kWave), __shfl(el.b, 0, kWave), __shfl(el.h, 0, kWave)});
+                        if (first < kWave) break;
                     }
-                    if (!ok) {
-                        hdr->error = 1u;
+                    if (ok) carry = apply(acc, (TC)0);
+                    else {
                         carry = (TC)__longlong_as_double(0x7ff8000000000000LL);
+                        if (lane == 0) hdr->error = 1u;
                     }
-                    lb_store(&myrec->x, lb_bits(apply(agg, carry)));
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    lb_store(&myrec->flag, 2ull);
+                    if (lane == 0) {
+                        lb_store(&myrec->x, lb_bits(apply(agg, carry)));
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        lb_store(&myrec->flag, 2ull);
+                    }
                 }
-                s_xc = carry;
-                s_xv = carry_v;
+                if (lane == 0) {
+                    s_xc = carry;
+                    s_xv = carry_v;
+                }
             }
             __syncthreads();
             xc = s_xc;
