@@ -70,7 +70,7 @@ const char *trl_last_kernel(void);
  * kernel's in-launch exchange); afterwards only this library writes it.  Calls that share a
  * workspace must not overlap in time (one workspace per stream).
  * Besides the statistics, the workspace carries the chunk records of the decoupled look-back scan:
- * when there are too few rows to fill the chip (O < #CUs / 2, I == 1, T of 8 chunks or more) and a
+ * when there are too few rows to fill the chip (O < 7/8 #CUs, I == 1, T of 8 chunks or more) and a
  * workspace of this size is passed, trl_gae_fwd (stats == NULL), trl_td_lambda_fwd and
  * trl_vtrace_fwd scan the chunks of a row in parallel; without a workspace they scan each row's
  * chunks in turn inside one block (same results). */

@@ -307,12 +307,12 @@ LOOKBACK_SHAPES = [(1, 100000, 1), (4, 50000, 1), (3, 8193, 1), (2, 16384, 1), (
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("shape", LOOKBACK_SHAPES, ids=[f"{s[0]}x{s[1]}" for s in LOOKBACK_SHAPES])
 def test_lookback_long_rows_vs_oracle(shape, dtype):
-    """Rows of 8 chunks or more with too few rows to fill the chip take the look-back kernel (all three
+    """Rows of 8 team chunks or more with too few rows to fill the chip take the look-back kernel (all three
     estimators, scalar and per-element gamma); same bar as the other SCAN kernels, and the result equals
     the in-block chunk loop's (the path taken when no workspace is passed) to the same bar."""
     r, v, nv, done, term, gam, lp, lm = _rand_inputs(shape, dtype, seed=5, p_term=0.001, p_trunc=0.001)
     chunk = 256 * (4 if dtype == torch.float32 else 2)
-    eligible = shape[1] >= 8 * chunk - chunk + 1
+    eligible = shape[1] >= 8 * chunk
     for gamma in (0.99, gam):
         oadv, ovt = O.gae(gamma, 0.95, v, nv, r, done, term)
         oret = O.td_lambda(gamma, 0.95, nv, r, done, term)

@@ -26,7 +26,7 @@ def timed(fn, n=50):
 
 
 for dtype in (torch.float32, torch.float64):
-    for O, T in [(1, 100000), (4, 50000), (1, 1 << 20), (8, 1 << 20), (64, 1 << 17), (300, 8192), (512, 8192), (1, 1 << 24)]:
+    for O, T in [(int(a), int(b)) for a, b in (x.split('x') for x in sys.argv[1:])] if len(sys.argv) > 1 else [(1, 100000), (4, 50000), (1, 1 << 20), (8, 1 << 20), (64, 1 << 17), (300, 8192), (512, 8192), (1, 1 << 24)]:
         shape = (O, T, 1)
         r, v, nv = (torch.randn(shape, device=dev, dtype=dtype) for _ in range(3))
         term = torch.rand(shape, device=dev) < 0.001

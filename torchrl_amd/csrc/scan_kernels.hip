@@ -295,7 +295,7 @@ __global__ __launch_bounds__(kLongThreads) void scan_long_kernel(typename Op::Ar
 }
 
 
-// ---- LONG rows, few of them: one chunk per block, decoupled look-back between chunks ----------------
+// ---- LONG rows, few of them: one chunk (4 teams) per block, decoupled look-back between chunks -------
 // When there are too few rows to fill the chip (O < ~2 * #CUs) a row's chunks are scanned in PARALLEL:
 // every block takes one chunk, publishes the chunk's aggregate map, then resolves its carry by
 // walking the records of the chunks that follow it in time ("look-back", here toward later time
@@ -333,32 +333,39 @@ __device__ __forceinline__ unsigned long long lb_load(const unsigned long long *
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+constexpr int kLbTeams = 4;  // teams per look-back block: one ticket / one record per 4 * 256 * V steps
+
 template <class Op, bool VEC>
-__global__ __launch_bounds__(kLongThreads) void scan_lookback_kernel(typename Op::Args args, ScanGeom geo, LbHeader *hdr,
-                                                                    LbRecord *rec) {
+__global__ __launch_bounds__(kLbTeams * kTeam) void scan_lookback_kernel(typename Op::Args args, ScanGeom geo, LbHeader *hdr,
+                                                                        LbRecord *rec) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
     constexpr int V = Op::V;
-    constexpr int kChunk = kLongThreads * V;
-    __shared__ TeamShared<Op> sh;
+    constexpr int kChunk = kTeam * V;            // steps per team
+    constexpr int kBlk = kLbTeams * kChunk;      // steps per block = per ticket = per record
+    __shared__ TeamShared<Op> sh[kLbTeams];
     __shared__ unsigned s_ticket;
-    __shared__ TC s_xc;
-    __shared__ TS s_xv;
+    __shared__ TC s_xc[kLbTeams];
+    __shared__ TS s_xv[kLbTeams];
     const unsigned T = (unsigned)geo.T;
-    const int lane_off = (int)threadIdx.x * V;
-    const int nchunks = (int)((geo.T + kChunk - 1) / kChunk);
+    const int team = threadIdx.x / kTeam;
+    const int lane_off = (int)(threadIdx.x & (kTeam - 1)) * V;
+    const int nchunks = (int)((geo.T + kBlk - 1) / kBlk);
 
+    // One ticket per block: the tickets serialise on one address (~13 ns each, measured), so they -- not HBM --
+    // bound the kernel unless a ticket covers enough bytes.
     if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&hdr->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const i64 k = s_ticket;
     const i64 row = k / nchunks;
     const int c = nchunks - 1 - (int)(k % nchunks);  // later chunks of a row draw earlier tickets
     if (row >= geo.O) return;
-    i64 cnt = geo.T - (i64)c * kChunk;
+    const i64 t_team = (i64)c * kBlk + (i64)team * kChunk;  // time index of the team's first step
+    i64 cnt = geo.T - t_team;
     if (cnt > kChunk) cnt = kChunk;
-    const i64 start = row * geo.T + (i64)c * kChunk;
+    if (cnt < 0) cnt = 0;
     const int nvalid = clamp_nvalid((int)cnt, lane_off, V);
-    const i64 flat = start + lane_off;
+    const i64 flat = row * geo.T + t_team + lane_off;
     LbRecord *myrec = rec + row * nchunks + c;
 
     typename Op::Raw raw;
@@ -369,25 +376,33 @@ __global__ __launch_bounds__(kLongThreads) void scan_lookback_kernel(typename Op
     TS Xv = (TS)0;
     double s = 0.0, ss = 0.0;
     scan_chunk<Op, false>(
-        op, sh, 0, nvalid, (unsigned)((i64)c * kChunk + lane_off), T, kWave, Xc, Xv,
+        op, sh[team], 0, nvalid, (unsigned)(t_team + lane_off), T, kWave, Xc, Xv,
         [&](const TC(&xs)[V], const bool(&row_end)[V], TC x_in, TS v_next) {
             typename Op::TO o0[V], o1[V];
             op.outputs(nvalid, xs, row_end, x_in, v_next, o0, o1, s, ss);
             store_outputs<Op, VEC>(args, flat, nvalid, o0, o1);
         },
-        [&](TeamShared<Op> &shm, int buf, TC &xc, TS &xv) {
-            if (threadIdx.x < kWave) {  // wave 0 resolves the carry: 64 records per look-back round
+        [&](TeamShared<Op> &, int buf, TC &xc, TS &xv) {
+            // every team's wave aggregates are in LDS (scan_chunk's barrier is block-wide)
+            if (threadIdx.x < kWave) {  // wave 0 resolves the carries: 64 records per look-back round
                 const int lane = threadIdx.x;
-                // this chunk's aggregate: x_first = G0(G1(G2(G3(x_in))))
-                Aff<TC> agg{shm.a[buf][kWaves - 1], shm.b[buf][kWaves - 1], shm.h[buf][kWaves - 1]};
+                Aff<TC> tagg[kLbTeams];  // team aggregates: x_first(team) = G0(G1(G2(G3(x_in))))
 #pragma unroll
-                for (int w = kWaves - 2; w >= 0; --w) agg = compose(Aff<TC>{shm.a[buf][w], shm.b[buf][w], shm.h[buf][w]}, agg);
-                const TS my_v0 = Op::kNeedsNext ? shm.v0[buf][0] : (TS)0;
+                for (int tm = 0; tm < kLbTeams; ++tm) {
+                    Aff<TC> g{sh[tm].a[buf][kWaves - 1], sh[tm].b[buf][kWaves - 1], sh[tm].h[buf][kWaves - 1]};
+#pragma unroll
+                    for (int w = kWaves - 2; w >= 0; --w) g = compose(Aff<TC>{sh[tm].a[buf][w], sh[tm].b[buf][w], sh[tm].h[buf][w]}, g);
+                    tagg[tm] = g;
+                }
+                Aff<TC> agg = tagg[kLbTeams - 1];
+#pragma unroll
+                for (int tm = kLbTeams - 2; tm >= 0; --tm) agg = compose(tagg[tm], agg);
+                const TS my_v0 = Op::kNeedsNext ? sh[0].v0[buf][0] : (TS)0;
                 TC carry = (TC)0;
                 TS carry_v = (TS)0;
                 bool ok = true;
                 if (agg.h) {
-                    // the chunk holds its row's end: inclusive value known at once
+                    // the block holds its row's end: inclusive value known at once
                     if (lane == 0) {
                         lb_store(&myrec->x, lb_bits(agg.b));
                         lb_store(&myrec->v0, lb_bits(my_v0));
@@ -446,13 +461,19 @@ __global__ __launch_bounds__(kLongThreads) void scan_lookback_kernel(typename Op
                     }
                 }
                 if (lane == 0) {
-                    s_xc = carry;
-                    s_xv = carry_v;
+                    // carries into the teams, last team first: what follows team tm is team tm+1 ... then `carry`
+                    TC x = carry;
+#pragma unroll
+                    for (int tm = kLbTeams - 1; tm >= 0; --tm) {
+                        s_xc[tm] = x;
+                        s_xv[tm] = (tm == kLbTeams - 1) ? carry_v : (Op::kNeedsNext ? sh[tm + 1 < kLbTeams ? tm + 1 : tm].v0[buf][0] : (TS)0);
+                        x = apply(tagg[tm], x);
+                    }
                 }
             }
             __syncthreads();
-            xc = s_xc;
-            xv = s_xv;
+            xc = s_xc[team];
+            xv = s_xv[team];
         });
 }
 
@@ -527,10 +548,11 @@ Plan make_plan(i64 O, i64 T, i64 I, int V, bool ptr_align_ok, int cus, size_t lb
         p.nblocks = O < kMaxLongGrid ? O : kMaxLongGrid;
         p.vec = ptr_align_ok && (T % V == 0);
         p.wave_indep = false;
-        // too few rows to fill the chip (measured crossover: ~#CUs/2 rows; the in-block chunk loop streams
+        // too few rows to fill the chip (measured crossover: ~0.9 * #CUs rows; the in-block chunk loop streams
         // ~13 GB/s per row): scan each row's chunks in parallel with decoupled look-back
-        const i64 nch = (T + chunk - 1) / chunk;
-        if (!want_partials && 2 * O < (i64)cus && nch >= 8 && O * nch <= (1LL << 22) &&
+        const i64 lb_chunk = chunk * kLbTeams;  // steps per look-back block
+        const i64 nch = (T + lb_chunk - 1) / lb_chunk;
+        if (!want_partials && 8 * O < 7 * (i64)cus && T >= 8 * chunk && O * nch <= (1LL << 22) &&
             lb_bytes >= sizeof(LbHeader) + (size_t)(O * nch) * sizeof(LbRecord)) {
             p.lookback = true;
             p.nchunks = nch;
@@ -555,8 +577,8 @@ LaunchResult launch_scan(hipStream_t s, const typename Op::Args &a, const Plan &
         LbRecord *rec = (LbRecord *)((char *)lb_ws + sizeof(LbHeader));
         if (hipMemsetAsync(lb_ws, 0, sizeof(LbHeader) + (size_t)p.nblocks * sizeof(LbRecord), s) != hipSuccess)
             return LaunchResult{4, 0, nullptr};
-        if (p.vec) hipLaunchKernelGGL((scan_lookback_kernel<Op, true>), grid, dim3(kLongThreads), 0, s, a, geo, hdr, rec);
-        else hipLaunchKernelGGL((scan_lookback_kernel<Op, false>), grid, dim3(kLongThreads), 0, s, a, geo, hdr, rec);
+        if (p.vec) hipLaunchKernelGGL((scan_lookback_kernel<Op, true>), grid, dim3(kLbTeams * kTeam), 0, s, a, geo, hdr, rec);
+        else hipLaunchKernelGGL((scan_lookback_kernel<Op, false>), grid, dim3(kLbTeams * kTeam), 0, s, a, geo, hdr, rec);
     } else if (p.long_rows) {
         if (p.vec) hipLaunchKernelGGL((scan_long_kernel<Op, true>), grid, dim3(kLongThreads), 0, s, a, geo, partials);
         else hipLaunchKernelGGL((scan_long_kernel<Op, false>), grid, dim3(kLongThreads), 0, s, a, geo, partials);
