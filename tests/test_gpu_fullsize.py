@@ -82,3 +82,43 @@ def test_c5_long_horizon_1024x10000(dt):
     adv, vt = F.generalized_advantage_estimate(c(gamma), 0.95, c(v), c(nv), c(r), c(done), c(term))
     _check_summary(adv, cs[f"C5_gae_{dt}"]["advantage"], te, te)
     _check_summary(vt, cs[f"C5_gae_{dt}"]["value_target"], te, te)
+
+
+@pytest.mark.parametrize("shape", [(70000, 32768, 1), ((1 << 26) + 5, 33, 1), (2200000, 200, 5)],
+                         ids=["70000x32768_long_rows", "67M_rows_x33", "2.2Mx200x5_feature_dim"])
+def test_more_than_2_31_transitions(shape):
+    """Maximum sizes: flat indices beyond 2^31 (2.2-2.3e9 transitions, ~50 GB of HBM).  Rows are independent,
+    so rows sampled from both ends and from around the 2^31st element are checked against the CPU oracle,
+    and the fp64 moments against torch's reduction of the device output."""
+    from oracle import value_oracle as O
+
+    O_, T, I = shape
+    n = O_ * T * I
+    assert n > (1 << 31)
+    free, _ = torch.cuda.mem_get_info()
+    if free < n * 30:
+        pytest.skip("needs ~70 GB of free HBM")
+    g = torch.Generator(device=DEV).manual_seed(7)
+    r, v, nv = (torch.randn(shape, generator=g, device=DEV) for _ in range(3))
+    term = torch.rand(shape, generator=g, device=DEV) < 0.002
+    done = term | (torch.rand(shape, generator=g, device=DEV) < 0.002)
+    adv, vt, st = F.gae_with_stats(0.99, 0.95, v, nv, r, done, term)
+    mid = (1 << 31) // (T * I)  # the row that contains flat element 2^31
+    rows = sorted({0, 1, 2, mid - 1, mid, mid + 1, O_ - 3, O_ - 2, O_ - 1})
+    idx = torch.tensor(rows, device=DEV)
+    pick = lambda t: t.index_select(0, idx).cpu()
+    oadv, ovt = O.gae(0.99, 0.95, pick(v), pick(nv), pick(r), pick(done), pick(term))
+    torch.testing.assert_close(pick(adv), oadv, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(pick(vt), ovt, rtol=1e-5, atol=1e-5)
+    d = pick(done)
+    assert torch.equal(pick(adv)[d], oadv[d])
+    # moments over all n elements (fp64, fixed order) vs torch, chunked to bound memory
+    s = ss = 0.0
+    for part in adv.flatten().split(1 << 28):
+        p64 = part.double()
+        s += float(p64.sum())
+        ss += float((p64 * p64).sum())
+    assert float(st[0]) == float(n)
+    assert abs(float(st[1]) - s) <= 1e-9 * n ** 0.5 * max(1.0, abs(s)) and abs(float(st[2]) - ss) <= 1e-10 * ss
+    # the tail of the flat array was written (a 32-bit index would have wrapped long before)
+    assert torch.isfinite(adv.flatten()[-(1 << 20):]).all() and bool((adv.flatten()[-(1 << 20):] != 0).any())
