@@ -25,6 +25,7 @@ have no counterpart here.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import struct
 import math
@@ -225,11 +226,25 @@ def _mask(m: torch.Tensor, shape, device=None) -> torch.Tensor:
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    # a plain int (or None) is what a c_void_p parameter converts fastest
+    return t.data_ptr() if t is not None else None
 
 
-def _stream(device) -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+def _stream(device) -> int:
+    """The caller's current hipStream_t on ``device`` as an integer handle."""
+    idx = device.index
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if idx is None else idx)
+
+
+_NO_GUARD = contextlib.nullcontext()
+
+
+def _on(device):
+    """Device guard for the native call -- free when ``device`` is already current (the common case)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
 
 
 def _needs_grad(*xs) -> bool:
@@ -318,7 +333,7 @@ def _workspace(lib, dev, O, T, I):
     """Per-(device, stream) workspace, zero-filled once (include/trl_value.h: it carries the
     epoch of the fused kernel's in-launch exchange); grown on demand."""
     need = lib.trl_workspace_bytes(O, T, I)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev))
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.zeros(max(need, 1 << 16), dtype=torch.uint8, device=dev)
@@ -350,7 +365,7 @@ def _launch_gae(c: _GaeCall, want_stats: bool = False, algo: int = ALGO_AUTO, ou
     else:
         ws = _lookback_workspace(lib, dev, c.O, c.T, c.I)
     ws_bytes = ws.numel() if ws is not None else 0
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.trl_gae_fwd(
             _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.value), _ptr(c.next_value),
             _ptr(c.done), _ptr(c.terminated), _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg,
@@ -378,7 +393,7 @@ def _launch_gae_normalize(c: _GaeCall, eps: float, algo: int = ALGO_AUTO, out=No
     head = (_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.value), _ptr(c.next_value),
             _ptr(c.done), _ptr(c.terminated), _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg,
             c.O, c.T, c.I, _ptr(adv), _ptr(vt), float(eps), _ptr(stats), _ptr(ws), ws.numel())
-    with torch.cuda.device(dev):
+    with _on(dev):
         if exchange is not None:
             rc = lib.trl_gae_normalize_xchg_fwd(*head, exchange.comm, algo)
         else:
@@ -699,7 +714,7 @@ def moments(x: torch.Tensor) -> torch.Tensor:
     n = xc.numel()
     ws = _workspace(lib, x.device, n, 1, 1)
     stats = torch.empty(3, dtype=torch.float64, device=x.device)
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.trl_moments(_stream(x.device), _DT[xc.dtype], _ptr(xc), n, _ptr(stats), _ptr(ws), ws.numel())
     _extension.check(rc, lib)
     return stats
@@ -717,7 +732,7 @@ def normalize_(x: torch.Tensor, stats: torch.Tensor, eps: float, out: Optional[t
     out = x if out is None else out
     if out.shape != x.shape or out.dtype != x.dtype or not out.is_contiguous():
         raise ValueError("normalize_: out must match x")
-    with torch.cuda.device(x.device):
+    with _on(x.device):
         rc = lib.trl_normalize(_stream(x.device), _DT[x.dtype], _ptr(x), x.numel(), _ptr(stats), float(eps), _ptr(out))
     _extension.check(rc, lib)
     return out
@@ -830,7 +845,7 @@ def _launch_td_lambda(c: _TdLambdaCall, out_dtype, algo: int = ALGO_AUTO) -> tor
     if c.O * c.T * c.I == 0:
         return out.to(out_dtype)
     ws = _lookback_workspace(lib, dev, c.O, c.T, c.I) if c.rolling else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.trl_td_lambda_fwd(
             _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.next_value), _ptr(c.done), _ptr(c.terminated),
             _ptr(c.gamma_t), _ptr(c.lmbda_t), c.gamma, c.lmbda, 1 if c.rolling else 0, c.O, c.T, c.I, _ptr(out),
@@ -1030,7 +1045,7 @@ def _launch_vtrace(c: _VtraceCall, algo: int = ALGO_AUTO):
     if c.O * c.T * c.I == 0:
         return adv, vs
     ws = _lookback_workspace(lib, dev, c.O, c.T, c.I)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = lib.trl_vtrace_fwd(
             _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.log_pi), _ptr(c.log_mu), _ptr(c.value), _ptr(c.next_value),
             _ptr(c.reward), _ptr(c.done), _ptr(c.terminated), _ptr(c.gamma_t), c.gamma, c.rho_thresh, c.c_thresh,
