@@ -1,0 +1,104 @@
+"""torchrl_amd.objectives.value.utils against golden vectors generated from the reference
+(tools/gen_golden_utils.py; reference: torchrl/objectives/value/utils.py) and the reference's own known
+answers (TestUtils, test/test_cost.py:16158-16285; docstring examples utils.py:101-110).  Index / padding
+results are exact; the correlation sums in a different order than conv1d (1e-6)."""
+import functools
+import json
+import operator
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from torchrl_amd.objectives.value.utils import (_custom_conv1d, _get_num_per_traj, _get_num_per_traj_init, _inv_pad_sequence,
+                                                _make_gammas_tensor, _split_and_pad_sequence, roll_by_gather)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MAN = json.load(open(os.path.join(HERE, "golden", "value_utils_manifest.json")))
+Z = np.load(os.path.join(HERE, "golden", "value_utils.npz"))
+DEVICES = ["cpu", pytest.param("cuda:0", marks=pytest.mark.gpu)]
+
+
+def arr(c, k, dev):
+    return torch.from_numpy(Z[f"{c['id']}.{k}"]).to(dev)
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+@pytest.mark.parametrize("c", MAN["cases"], ids=[f"{c['id']}-{c['fn']}" for c in MAN["cases"]])
+def test_against_reference_goldens(c, dev):
+    a = functools.partial(arr, c, dev=dev)
+    if c["fn"] == "roll_by_gather":
+        assert torch.equal(roll_by_gather(a("mat"), c["dim"], a("shifts")), a("out"))
+    elif c["fn"] == "_make_gammas_tensor":
+        assert torch.equal(_make_gammas_tensor(a("gamma"), c["T"], c["rolling_gamma"]), a("out"))
+    elif c["fn"] == "_custom_conv1d":
+        torch.testing.assert_close(_custom_conv1d(a("tensor"), a("filter")), a("out"), rtol=1e-6, atol=1e-6)
+    else:
+        splits = _get_num_per_traj(a("done"))
+        assert torch.equal(splits, a("splits"))
+        padded, mask = _split_and_pad_sequence(a("traj"), splits, return_mask=True)
+        assert torch.equal(padded, a("padded")) and torch.equal(mask, a("mask"))
+        assert torch.equal(_inv_pad_sequence(padded, splits), a("unpadded"))
+        assert torch.equal(_split_and_pad_sequence(a("feat"), splits, time_dim=-2), a("padded_feat"))
+        assert torch.equal(_get_num_per_traj_init(a("is_init")), a("splits_init"))
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_roll_by_gather_docstring(dev):
+    x = torch.arange(12, device=dev).view(3, 4)
+    assert roll_by_gather(x, 0, -torch.arange(4, device=dev)).tolist() == [[0, 5, 10, 3], [4, 9, 2, 7], [8, 1, 6, 11]]
+    assert roll_by_gather(x, 1, -torch.arange(3, device=dev)).tolist() == [[0, 1, 2, 3], [5, 6, 7, 4], [10, 11, 8, 9]]
+    with pytest.raises(NotImplementedError, match="dim 2 is not supported"):
+        roll_by_gather(x, 2, torch.zeros(3, dtype=torch.long, device=dev))
+
+
+@pytest.mark.parametrize("dev", DEVICES)
+def test_split_pad_manual(dev):
+    """test_cost.py:16245-16255"""
+    traj = torch.as_tensor([[0, 1, 2, 3, 4], [5, 6, 7, 8, 9]], device=dev)
+    splits = torch.as_tensor([3, 2, 1, 4], device=dev)
+    want = torch.as_tensor([[0, 1, 2, 0], [3, 4, 0, 0], [5, 0, 0, 0], [6, 7, 8, 9]], device=dev)
+    assert torch.equal(_split_and_pad_sequence(traj, splits), want)
+
+
+@pytest.mark.parametrize("B", [(1,), (3,), (2, 2), (1, 2, 8)])
+@pytest.mark.parametrize("T", [5, 100])
+def test_num_per_traj_and_round_trip(B, T):
+    """test_cost.py:16176-16243: no stops, a stop at T//2, split -> pad -> un-pad round trip, no-stop flatten."""
+    count = functools.reduce(operator.mul, B, 1)
+    done = torch.zeros(*B, T, dtype=torch.bool)
+    assert torch.equal(_get_num_per_traj(done), torch.full((count,), T))
+    traj = torch.arange(count * T).reshape(*B, T)
+    assert torch.equal(_split_and_pad_sequence(traj, _get_num_per_traj(done)), traj.flatten(0, -2))
+    done[..., T // 2] = True
+    assert _get_num_per_traj(done).tolist() == [T - (T + 1) // 2 + 1, (T + 1) // 2 - 1] * count
+    torch.manual_seed(42)
+    x = torch.rand(*B, T)
+    done = torch.zeros(*B, T, dtype=torch.bool).bernoulli(0.2)
+    splits = _get_num_per_traj(done)
+    assert torch.equal(_inv_pad_sequence(_split_and_pad_sequence(x, splits), splits).reshape(x.shape), x)
+
+
+def test_split_pad_mapping_and_init_docstring():
+    """utils.py:226-285 (tensordict example, here a mapping of tensors) and test_cost.py:16258-16285."""
+    is_init = torch.zeros(4, 5, dtype=torch.bool)
+    is_init[:, 0] = True
+    is_init[0, 3] = True
+    is_init[1, 2] = True
+    splits = _get_num_per_traj_init(is_init)
+    assert splits.tolist() == [3, 2, 2, 3, 5, 5]
+    obs = torch.arange(20).view(4, 5).unsqueeze(-1).expand(4, 5, 3)
+    out = _split_and_pad_sequence({"obs": obs, "is_init": is_init.unsqueeze(-1)}, splits, time_dim=-2)
+    assert out["obs"].shape == (6, 5, 3) and out["obs"][0, :, 0].tolist() == [0, 1, 2, 0, 0] and out["obs"][3, :, 0].tolist() == [7, 8, 9, 0, 0]
+    back = _inv_pad_sequence(out, splits)
+    assert torch.equal(back["obs"].reshape(4, 5, 3), obs)
+
+
+def test_custom_conv1d_is_a_discounted_return():
+    """utils.py:17-27: filter [1, g, g^2, g^3] over rewards gives the discounted return."""
+    r = torch.tensor([[[1.0, 2.0, 3.0, 4.0]]])
+    gam = 0.5
+    out = _custom_conv1d(r, torch.tensor([1.0, gam, gam ** 2, gam ** 3]).unsqueeze(-1))
+    want = [1 + gam * 2 + gam ** 2 * 3 + gam ** 3 * 4, 2 + gam * 3 + gam ** 2 * 4, 3 + gam * 4, 4]
+    torch.testing.assert_close(out.flatten(), torch.tensor(want))
