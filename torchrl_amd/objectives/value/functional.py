@@ -556,6 +556,21 @@ class _VtraceFunction(torch.autograd.Function):
         return tuple(res) + (None,)
 
 
+def _geom_series_like(t: torch.Tensor, r, thr: float) -> torch.Tensor:
+    """``[1, r, r**2, ...]`` as a ``[len, 1]`` column with ``t``'s dtype / device, cut where ``r**k`` falls
+    under ``thr`` (reference: functional.py:185-210 -- the filter of the reference's conv1d estimators; the
+    scan kernels here never truncate, this is kept for the module's surface).  ``r == 0`` gives zeros of
+    ``t``'s shape, ``r >= 1`` the full length of ``t``."""
+    if isinstance(r, torch.Tensor):
+        r = r.item()
+    if r == 0.0:
+        return torch.zeros_like(t)
+    lim = t.numel() if r >= 1.0 else int(math.log(thr) / math.log(r))
+    ratios = torch.full_like(t[:lim], r)
+    ratios[0] = 1.0
+    return ratios.cumprod(0).unsqueeze(-1)   # cumulative products, as the reference forms them (not r**k)
+
+
 def _no_coef_grad(name, *coefs):
     for x in coefs:
         if isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled():
