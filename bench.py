@@ -94,7 +94,7 @@ def main():
         try:
             pr = subprocess.run([sys.executable, "-m", "torchrl_amd.objectives.value.stats_exchange", store], cwd=ROOT,
                                 env=dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", "")),
-                                capture_output=True, text=True, timeout=240)
+                                capture_output=True, text=True, timeout=120)
             probe_ok = pr.returncode == 0
             if not probe_ok and rank == 0:
                 print("bench: exchange probe failed:\n" + pr.stdout[-2000:] + pr.stderr[-2000:], file=sys.stderr)

@@ -170,7 +170,9 @@ def _probe_main(store_path: str) -> int:
     dev = torch.device("cuda", local)
     torch.zeros(1, device=dev)  # device context up before anything else
     store = td.FileStore(store_path, world)
-    td.init_process_group("gloo", store=store, rank=rank, world_size=world)
+    import datetime
+
+    td.init_process_group("gloo", store=store, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=45))
     good = False
     try:
         ex = StatsExchange.create(device=dev, timeout_s=5.0)
