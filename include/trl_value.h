@@ -75,6 +75,11 @@ const char *trl_last_kernel(void);
  * trl_vtrace_fwd scan the chunks of a row in parallel; without a workspace they scan each row's
  * chunks in turn inside one block (same results). */
 size_t trl_workspace_bytes(int64_t O, int64_t T, int64_t I);
+/* 1 if a single-launch (FUSED) call on this workspace ever gave up waiting for its other blocks (its
+ * grid of #CUs persistent blocks must be co-resident: a GPU shared with other long-running kernels
+ * can starve it; the wait is bounded at 1 s and the outputs are then NaN), 0 if not, -1 on error.
+ * Synchronises the device. */
+int trl_workspace_error(const void *workspace);
 
 /*
  * Generalized advantage estimate.

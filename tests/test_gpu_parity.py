@@ -385,3 +385,10 @@ def test_empty_inputs_give_empty_outputs(shape):
     assert va.shape == vs.shape == torch.Size(shape)
     adv, vt = F.gae_normalized(0.9, 0.9, z, z, z, d, d)
     assert adv.shape == torch.Size(shape)
+
+
+def test_workspace_error_word_is_clear_after_fused_calls():
+    r, v, nv, done, term, gam, lp, lm = (cu(t) for t in _rand_inputs((2048, 32, 1), torch.float32, seed=4))
+    adv, vt = F.gae_normalized(0.99, 0.95, v, nv, r, done, term)
+    assert F.last_kernel() == "gae_fused" and torch.isfinite(adv).all()
+    assert F.workspace_error() is False

@@ -43,6 +43,7 @@ _PROTOTYPES = {
     "trl_last_error": (ctypes.c_char_p, []),
     "trl_last_kernel": (ctypes.c_char_p, []),
     "trl_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "trl_workspace_error": (_int, [_vp]),
     "trl_gae_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl,
                            _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _int]),
     "trl_gae_normalize_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl,

@@ -85,6 +85,15 @@ size_t trl_workspace_bytes(int64_t O, int64_t T, int64_t I) {
     return lookback_offset(O, T, I) + scan_lookback_bytes(O, T, I) + 256;
 }
 
+int trl_workspace_error(const void *workspace) {
+    if (!workspace) return -1;
+    // fused-kernel header: {epoch, error, ...}; the look-back header sits behind the partials and is
+    // re-zeroed by every launch, so only the fused word persists
+    unsigned words[2] = {0, 0};
+    if (hipMemcpy(words, workspace, sizeof(words), hipMemcpyDeviceToHost) != hipSuccess) return -1;  // synchronises
+    return words[1] != 0 ? 1 : 0;
+}
+
 int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
                 const void *next_state_value, const uint8_t *done, const uint8_t *terminated,
                 const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,

@@ -341,6 +341,15 @@ def _workspace(lib, dev, O, T, I):
     return ws
 
 
+def workspace_error(device=None) -> bool:
+    """True if a single-launch GAE + normalise on ``device``'s current stream ever timed out waiting for its
+    other blocks (the persistent grid needs the whole GPU; outputs of such a call are NaN).  Synchronises."""
+    lib = _extension.get_lib()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    ws = _WORKSPACES.get((dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev)))
+    return ws is not None and lib.trl_workspace_error(_ptr(ws)) == 1
+
+
 def _lookback_workspace(lib, dev, O, T, I):
     """Workspace for the decoupled look-back scan of few, very long rows (trl_value.h:
     trl_workspace_bytes); None for every other shape (the library then needs none)."""
