@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TRL_ABI_VERSION 2
+#define TRL_ABI_VERSION 3
 
 enum { TRL_F32 = 0, TRL_F64 = 1 };
 
@@ -92,13 +92,17 @@ int trl_workspace_error(const void *workspace);
  *   when gamma_t != NULL and lg_t == NULL, lg_t is formed as (coef)lmbda * gamma_t in-kernel
  *   (what `lmbda * gamma` gives for a python-float lmbda).  When both are NULL the scalars
  *   `gamma` and `lg` apply.
+ * mask_bcast: 0 = done / terminated are full (O, T, I) arrays; 1 = they are (O, T) arrays shared by
+ *   the I feature elements of a step (what a stride-0 `expand` of a per-env mask over the agent
+ *   dimension means, sota-implementations/multiagent/utils/utils.py:34-43) and are read in place.
+ *   Ignored when I == 1.  Same meaning in every entry point below.
  * stats (optional, device double[3]): receives {N, sum(A), sum(A^2)} accumulated in fp64 in a
  *   fixed order (deterministic); needs `workspace` of trl_workspace_bytes().  It feeds
  *   trl_normalize() (after an all-reduce when the batch is sharded over GPUs).
  */
 int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype,
                 const void *reward, const void *state_value, const void *next_state_value,
-                const uint8_t *done, const uint8_t *terminated,
+                const uint8_t *done, const uint8_t *terminated, int mask_bcast,
                 const void *gamma_t, const void *lg_t,
                 double gamma, double lmbda, double lg,
                 int64_t O, int64_t T, int64_t I,
@@ -118,7 +122,7 @@ int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype,
  */
 int trl_gae_normalize_fwd(void *stream, int val_dtype, int coef_dtype,
                           const void *reward, const void *state_value, const void *next_state_value,
-                          const uint8_t *done, const uint8_t *terminated,
+                          const uint8_t *done, const uint8_t *terminated, int mask_bcast,
                           const void *gamma_t, const void *lg_t,
                           double gamma, double lmbda, double lg,
                           int64_t O, int64_t T, int64_t I,
@@ -138,7 +142,7 @@ int trl_gae_normalize_fwd(void *stream, int val_dtype, int coef_dtype,
  */
 int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype,
                       const void *reward, const void *next_state_value,
-                      const uint8_t *done, const uint8_t *terminated,
+                      const uint8_t *done, const uint8_t *terminated, int mask_bcast,
                       const void *gamma_t, const void *lmbda_t,
                       double gamma, double lmbda, int rolling_gamma,
                       int64_t O, int64_t T, int64_t I,
@@ -157,7 +161,7 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype,
 int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype,
                    const void *log_pi, const void *log_mu,
                    const void *state_value, const void *next_state_value, const void *reward,
-                   const uint8_t *done, const uint8_t *terminated,
+                   const uint8_t *done, const uint8_t *terminated, int mask_bcast,
                    const void *gamma_t, double gamma, double rho_thresh, double c_thresh,
                    int64_t O, int64_t T, int64_t I,
                    void *advantage, void *vs, void *workspace, size_t workspace_bytes, int algo);
@@ -244,7 +248,7 @@ int trl_xchg_error(void *comm);
 int trl_xchg_destroy(void *comm, void *mailbox);
 int trl_gae_normalize_xchg_fwd(void *stream, int val_dtype, int coef_dtype,
                                const void *reward, const void *state_value, const void *next_state_value,
-                               const uint8_t *done, const uint8_t *terminated,
+                               const uint8_t *done, const uint8_t *terminated, int mask_bcast,
                                const void *gamma_t, const void *lg_t,
                                double gamma, double lmbda, double lg,
                                int64_t O, int64_t T, int64_t I,

@@ -392,3 +392,47 @@ def test_workspace_error_word_is_clear_after_fused_calls():
     adv, vt = F.gae_normalized(0.99, 0.95, v, nv, r, done, term)
     assert F.last_kernel() == "gae_fused" and torch.isfinite(adv).all()
     assert F.workspace_error() is False
+
+
+BCAST = [((40, 50, 5, 1), -3), ((6, 9, 2, 5), 1), ((33, 17, 64), -2), ((4096, 100, 5, 1), -3), ((7, 3, 2), -2), ((50, 16, 4), -2),
+         ((19, 101, 3), -2), ((64, 25, 4), 1), ((4, 300, 130), -2)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape,time_dim", BCAST, ids=["x".join(map(str, s)) for s, _ in BCAST])
+def test_broadcast_masks_read_in_place(shape, time_dim, dtype):
+    """Per-env masks `expand`ed over the feature / agent dims (stride 0, as DoneTransform produces) go to the
+    kernels as compact [*B, T] arrays (mask_bcast = 1): SEQ bit-exact, the interleaved SCAN kernel within
+    tolerance, all three estimators; equal to what the materialised masks give."""
+    r, v, nv, _, _, gam, lp, lm = _rand_inputs(shape, dtype, seed=21)
+    td = time_dim if time_dim < 0 else time_dim - len(shape)
+    mshape = tuple(shape[:len(shape) + td + 1]) + (1,) * (-td - 1)
+    g = torch.Generator().manual_seed(5)
+    term_c = torch.rand(mshape, generator=g) < 0.03
+    done_c = term_c | (torch.rand(mshape, generator=g) < 0.03)
+    term, done = term_c.expand(shape), done_c.expand(shape)
+    oadv, ovt = O.gae(0.9, 0.9, v, nv, r, done, term, time_dim=time_dim)
+    oret = O.td_lambda(gam, 0.9, nv, r, done, term, time_dim=time_dim)
+    ova, ovs = O.vtrace(0.9, lp, lm, v, nv, r, done, term, time_dim=time_dim)
+    dd, tt = cu(done_c).expand(shape), cu(term_c).expand(shape)
+    gcall = F._prepare_gae(0.9, 0.9, cu(v), cu(nv), cu(r), dd, tt, time_dim)
+    tcall = F._prepare_td_lambda(cu(gam), 0.9, cu(nv), cu(r), dd, tt, None, time_dim)
+    vcall = F._prepare_vtrace(0.9, cu(lp), cu(lm), cu(v), cu(nv), cu(r), dd, tt, 1.0, 1.0, time_dim)
+    assert gcall.mask_bcast == tcall.mask_bcast == vcall.mask_bcast == 1
+    for algo in algos(gcall):
+        adv, vt, st = F._launch_gae(gcall, want_stats=True, algo=algo)
+        check(adv, oadv, algo == SEQ, done)
+        check(vt, ovt, algo == SEQ, done)
+        check(F._launch_td_lambda(tcall, dtype, algo=algo), oret, algo == SEQ)
+        va, vs = F._launch_vtrace(vcall, algo=algo)
+        check(va, ova, False)
+        check(vs, ovs, False)
+    # public entry points, and the normalised form (not fused for I > 1: scan + normalise)
+    adv, vt = F.generalized_advantage_estimate(0.9, 0.9, cu(v), cu(nv), cu(r), dd, tt, time_dim=time_dim)
+    check(adv, oadv, False, done)
+    nadv, _ = F.gae_normalized(0.9, 0.9, cu(v), cu(nv), cu(r), dd, tt, time_dim=time_dim)
+    torch.testing.assert_close(nadv.cpu(), O.normalize(oadv, 1e-4), rtol=2e-5, atol=2e-5)
+    # rolling_gamma=False (O(T^2) SEQ kernel) reads the compact masks too
+    if shape[len(shape) + td] <= 50:
+        got = F.td_lambda_return_estimate(cu(gam), 0.9, cu(nv), cu(r), dd, tt, rolling_gamma=False, time_dim=time_dim)
+        check(got, O.td_lambda(gam, 0.9, nv, r, done, term, rolling_gamma=False, time_dim=time_dim), True)

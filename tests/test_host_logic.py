@@ -122,12 +122,28 @@ def test_td_lambda_coefficients_keep_value_dtype():
     assert c.gamma == float(torch.tensor(0.99, dtype=torch.float32))
 
 
-def test_expanded_masks_are_materialised():
+def test_expanded_masks_are_handed_over_compact():
+    """Stride-0 masks over the agent dim (DoneTransform) are read in place by the kernels (mask_bcast = 1):
+    no materialisation; anything else -- or an input that needs gradients -- takes the full layout."""
     r = torch.randn(4, 10, 5, 1)
-    d = (torch.rand(4, 10, 1, 1) < 0.2).expand(4, 10, 5, 1)
+    base = torch.rand(4, 10, 1, 1) < 0.2
+    d = base.expand(4, 10, 5, 1)
     c = F._prepare_gae(0.9, 0.9, r, r, r, d, d, -3)
-    assert c.done.is_contiguous() and c.done.dtype == torch.uint8 and c.done.shape == r.shape
-    assert (c.O, c.T, c.I) == (4, 10, 5)
+    assert (c.O, c.T, c.I, c.mask_bcast) == (4, 10, 5, 1)
+    assert c.done.is_contiguous() and c.done.dtype == torch.uint8 and c.done.shape == (4, 10)
+    assert c.done.data_ptr() == base.data_ptr()  # a view of the caller's mask, not a copy
+    t = F._prepare_td_lambda(0.9, 0.9, r, r, d, d, None, -3)
+    v = F._prepare_vtrace(0.9, r, r, r, r, r, d, d, 1.0, 1.0, -3)
+    assert t.mask_bcast == 1 and v.mask_bcast == 1 and v.done.shape == (4, 10)
+    # one full mask, or a dense mask: materialised in the canonical layout
+    full = torch.rand(4, 10, 5, 1) < 0.2
+    for dd, tt in ((d, full), (full, full)):
+        c = F._prepare_gae(0.9, 0.9, r, r, r, dd, tt, -3)
+        assert c.mask_bcast == 0 and c.done.shape == r.shape and c.done.is_contiguous() and c.done.dtype == torch.uint8
+    rg = r.clone().requires_grad_(True)
+    assert F._prepare_gae(0.9, 0.9, rg, r, r, d, d, -3).mask_bcast == 0
+    # I == 1: nothing to broadcast over
+    assert F._prepare_gae(0.9, 0.9, r[:, :, :1], r[:, :, :1], r[:, :, :1], base, base, -3).mask_bcast == 0
 
 
 def test_vtrace_thresholds_round_like_torch_tensor():

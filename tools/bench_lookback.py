@@ -35,7 +35,7 @@ for dtype in (torch.float32, torch.float64):
         adv, vt = torch.empty_like(v), torch.empty_like(v)
         ws = F._workspace(lib, dev, O, T, 1)
         head = (F._stream(dev), F._DT[c.vdt], F._DT[c.cdt], F._ptr(c.reward), F._ptr(c.value), F._ptr(c.next_value),
-                F._ptr(c.done), F._ptr(c.terminated), None, None, c.gamma, c.lmbda, c.lg, O, T, 1, F._ptr(adv), F._ptr(vt), None)
+                F._ptr(c.done), F._ptr(c.terminated), 0, None, None, c.gamma, c.lmbda, c.lg, O, T, 1, F._ptr(adv), F._ptr(vt), None)
         res = {}
         for name, tail in (("lookback", (F._ptr(ws), ws.numel(), F.ALGO_SCAN)), ("chunk_loop", (None, 0, F.ALGO_SCAN))):
             us = timed(lambda: lib.trl_gae_fwd(*head, *tail))

@@ -18,7 +18,7 @@ import warnings
 
 _LIB_NAME = "libtrl_value.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EXTENSION_WARNING = (
     f"Failed to load the torchrl_amd HIP library ({_LIB_PATH}). The value estimators "
@@ -44,13 +44,13 @@ _PROTOTYPES = {
     "trl_last_kernel": (ctypes.c_char_p, []),
     "trl_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "trl_workspace_error": (_int, [_vp]),
-    "trl_gae_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl,
+    "trl_gae_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _dbl,
                            _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _int]),
-    "trl_gae_normalize_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl,
+    "trl_gae_normalize_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _dbl,
                                      _i64, _i64, _i64, _vp, _vp, _dbl, _vp, _vp, _sz, _int]),
-    "trl_td_lambda_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _int,
+    "trl_td_lambda_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _int,
                                  _i64, _i64, _i64, _vp, _vp, _sz, _int]),
-    "trl_vtrace_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl,
+    "trl_vtrace_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _dbl, _dbl, _dbl,
                               _i64, _i64, _i64, _vp, _vp, _vp, _sz, _int]),
     "trl_normalize": (_int, [_vp, _int, _vp, _i64, _vp, _dbl, _vp]),
     "trl_moments": (_int, [_vp, _int, _vp, _i64, _vp, _vp, _sz]),
@@ -63,7 +63,7 @@ _PROTOTYPES = {
     "trl_xchg_allreduce_stats": (_int, [_vp, _vp, _vp]),
     "trl_xchg_set_timeout": (_int, [_vp, _dbl]),
     "trl_xchg_error": (_int, [_vp]),
-    "trl_gae_normalize_xchg_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl,
+    "trl_gae_normalize_xchg_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _dbl,
                                           _i64, _i64, _i64, _vp, _vp, _dbl, _vp, _vp, _sz, _vp, _int]),
     "trl_xchg_destroy": (_int, [_vp, _vp]),
 }

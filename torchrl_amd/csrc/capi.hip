@@ -95,7 +95,7 @@ int trl_workspace_error(const void *workspace) {
 }
 
 int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
-                const void *next_state_value, const uint8_t *done, const uint8_t *terminated,
+                const void *next_state_value, const uint8_t *done, const uint8_t *terminated, int mask_bcast,
                 const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
                 int64_t O, int64_t T, int64_t I, void *advantage, void *value_target,
                 double *stats, void *workspace, size_t workspace_bytes, int algo) {
@@ -111,7 +111,8 @@ int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward,
         if (((uintptr_t)workspace & 7) != 0) return fail(TRL_ERR_WORKSPACE, "trl_gae_fwd: workspace must be 8-byte aligned");
     }
     GaeArgs a{reward, state_value, next_state_value, done, terminated, gamma_t, lg_t, gamma, lmbda, lg,
-              O, T, I, advantage, value_target, stats ? (double *)((char *)workspace + kWsPartialsOffset) : nullptr};
+              O, T, I, advantage, value_target, stats ? (double *)((char *)workspace + kWsPartialsOffset) : nullptr,
+              (mask_bcast && I > 1) ? 1 : 0};
     hipStream_t s = (hipStream_t)stream;
     if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ)
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: unknown algo %d", algo);
@@ -134,7 +135,7 @@ int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward,
 }
 
 int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *next_state_value,
-                      const uint8_t *done, const uint8_t *terminated, const void *gamma_t, const void *lmbda_t,
+                      const uint8_t *done, const uint8_t *terminated, int mask_bcast, const void *gamma_t, const void *lmbda_t,
                       double gamma, double lmbda, int rolling_gamma, int64_t O, int64_t T, int64_t I,
                       void *returns, void *workspace, size_t workspace_bytes, int algo) {
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td_lambda_fwd: bad dtype");
@@ -143,7 +144,8 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype, const void *r
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td_lambda_fwd: null tensor pointer");
     if (!rolling_gamma && !gamma_t && !lmbda_t)
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td_lambda_fwd: rolling_gamma=0 needs a gamma or lmbda tensor");
-    TdLambdaArgs a{reward, next_state_value, done, terminated, gamma_t, lmbda_t, gamma, lmbda, O, T, I, returns};
+    TdLambdaArgs a{reward, next_state_value, done, terminated, gamma_t, lmbda_t, gamma, lmbda, O, T, I, returns,
+                   (mask_bcast && I > 1) ? 1 : 0};
     hipStream_t s = (hipStream_t)stream;
     LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
     if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ)
@@ -162,7 +164,7 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype, const void *r
 
 int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_pi, const void *log_mu,
                    const void *state_value, const void *next_state_value, const void *reward,
-                   const uint8_t *done, const uint8_t *terminated, const void *gamma_t, double gamma,
+                   const uint8_t *done, const uint8_t *terminated, int mask_bcast, const void *gamma_t, double gamma,
                    double rho_thresh, double c_thresh, int64_t O, int64_t T, int64_t I,
                    void *advantage, void *vs, void *workspace, size_t workspace_bytes, int algo) {
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_fwd: bad dtype");
@@ -170,7 +172,7 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_
     if (!log_pi || !log_mu || !state_value || !next_state_value || !reward || !done || !terminated || !advantage || !vs)
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_fwd: null tensor pointer");
     VtraceArgs a{log_pi, log_mu, state_value, next_state_value, reward, done, terminated, gamma_t,
-                 gamma, rho_thresh, c_thresh, O, T, I, advantage, vs};
+                 gamma, rho_thresh, c_thresh, O, T, I, advantage, vs, (mask_bcast && I > 1) ? 1 : 0};
     hipStream_t s = (hipStream_t)stream;
     LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
     if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ)
@@ -188,7 +190,7 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_
 }
 
 static int gae_normalize_impl(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
-                              const void *next_state_value, const uint8_t *done, const uint8_t *terminated,
+                              const void *next_state_value, const uint8_t *done, const uint8_t *terminated, int mask_bcast,
                               const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
                               int64_t O, int64_t T, int64_t I, void *advantage, void *value_target, double eps,
                               double *stats, void *workspace, size_t workspace_bytes, void *comm, int algo) {
@@ -205,7 +207,7 @@ static int gae_normalize_impl(void *stream, int val_dtype, int coef_dtype, const
     hipStream_t s = (hipStream_t)stream;
     if (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_FUSED) {
         GaeArgs a{reward, state_value, next_state_value, done, terminated, gamma_t, lg_t, gamma, lmbda, lg,
-                  O, T, I, advantage, value_target, nullptr};
+                  O, T, I, advantage, value_target, nullptr, 0};
         LaunchResult res = launch_gae_fused(s, val_dtype, coef_dtype, a, eps, workspace, stats, comm);
         if (res.status == 0) {
             if (int rc = check_launch("trl_gae_normalize_fwd(fused)")) return rc;
@@ -218,8 +220,8 @@ static int gae_normalize_impl(void *stream, int val_dtype, int coef_dtype, const
                                              "4 chunks per team (advantages are kept in registers)");
     }
     double *st = stats ? stats : (double *)((char *)workspace + kWsStatsOffset);
-    if (int rc = trl_gae_fwd(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated, gamma_t,
-                             lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, st, workspace, workspace_bytes,
+    if (int rc = trl_gae_fwd(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated, mask_bcast,
+                             gamma_t, lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, st, workspace, workspace_bytes,
                              algo == TRL_ALGO_FUSED ? TRL_ALGO_AUTO : algo))
         return rc;
     if (comm)
@@ -228,23 +230,23 @@ static int gae_normalize_impl(void *stream, int val_dtype, int coef_dtype, const
 }
 
 int trl_gae_normalize_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
-                          const void *next_state_value, const uint8_t *done, const uint8_t *terminated,
+                          const void *next_state_value, const uint8_t *done, const uint8_t *terminated, int mask_bcast,
                           const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
                           int64_t O, int64_t T, int64_t I, void *advantage, void *value_target, double eps,
                           double *stats, void *workspace, size_t workspace_bytes, int algo) {
-    return gae_normalize_impl(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated, gamma_t,
-                              lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, eps, stats, workspace,
+    return gae_normalize_impl(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated,
+                              mask_bcast, gamma_t, lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, eps, stats, workspace,
                               workspace_bytes, nullptr, algo);
 }
 
 int trl_gae_normalize_xchg_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
-                               const void *next_state_value, const uint8_t *done, const uint8_t *terminated,
+                               const void *next_state_value, const uint8_t *done, const uint8_t *terminated, int mask_bcast,
                                const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
                                int64_t O, int64_t T, int64_t I, void *advantage, void *value_target, double eps,
                                double *stats, void *workspace, size_t workspace_bytes, void *comm, int algo) {
     if (!comm) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_normalize_xchg_fwd: null communicator");
-    return gae_normalize_impl(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated, gamma_t,
-                              lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, eps, stats, workspace,
+    return gae_normalize_impl(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated,
+                              mask_bcast, gamma_t, lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, eps, stats, workspace,
                               workspace_bytes, comm, algo);
 }
 

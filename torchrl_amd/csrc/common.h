@@ -92,6 +92,7 @@ struct GaeArgs {
     i64 O, T, I;
     void *advantage, *value_target;
     double *partials;  // optional: per-block {sum, sumsq} of advantage
+    int mask_bcast;    // 1: done / terminated are (O, T) arrays shared by the I feature elements of a step
 };
 
 struct TdLambdaArgs {
@@ -101,6 +102,7 @@ struct TdLambdaArgs {
     double gamma, lmbda;
     i64 O, T, I;
     void *returns;
+    int mask_bcast;
 };
 
 struct VtraceArgs {
@@ -110,6 +112,7 @@ struct VtraceArgs {
     double gamma, rho_thresh, c_thresh;
     i64 O, T, I;
     void *advantage, *vs;
+    int mask_bcast;
 };
 
 // Host-side launchers (defined in the .hip files, called from capi.hip).  Each returns the

@@ -141,17 +141,20 @@ __global__ __launch_bounds__(kTeam, IL_WAVES) void scan_interleaved_kernel(typen
 
     // virtual (row-major per (o,i)) position of this lane's first element inside a chunk, and the
     // physical in-chunk offset of each of its V elements
-    int pe[V];
+    int pe[V], pm[V];  // pm: offset of the step's mask byte when the masks are shared by the I feature elements
     {
         unsigned rv = (unsigned)lane_off / T, t = (unsigned)lane_off % T;
         unsigned ol = rv / (unsigned)I, i = rv % (unsigned)I;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
             pe[e] = (int)((ol * T + t) * (unsigned)I + i);
+            pm[e] = (int)(ol * T + t);
             if (++t == T) { t = 0; if (++i == (unsigned)I) { i = 0; ++ol; } }
         }
     }
     const unsigned t0 = (unsigned)lane_off % T;
+    const bool bcast = args.mask_bcast != 0;
+    const bool mvec = VEC && ((geo.rows_per_chunk * geo.T) % 4 == 0);  // mask chunk starts stay dword-aligned
 
     auto geom_of = [&](i64 c, i64 &start, int &count) {
         const i64 row0 = c * geo.rows_per_chunk;
@@ -173,7 +176,18 @@ __global__ __launch_bounds__(kTeam, IL_WAVES) void scan_interleaved_kernel(typen
         geom_of(c, start, count);
         const int nvalid = clamp_nvalid(count, lane_off, V);
         typename Op::Raw cur;
-        load_inputs<Op, VEC>(args, start + lane_off, nvalid, cur);
+        Op::for_each_input(args, cur, [&](auto *base, auto &arr) {
+            typedef typename std::remove_reference<decltype(arr[0])>::type E;
+            if (!base) return;
+            if (sizeof(E) == 1 && bcast) {  // (count / I) mask bytes, one per step of the chunk's outer rows
+                const i64 mstart = c * geo.rows_per_chunk * geo.T;  // = start / I without the division
+                const int mvalid = clamp_nvalid((int)(count == (int)(geo.rows_per_chunk * row_elems) ? geo.rows_per_chunk * geo.T : count / I), lane_off, V);
+                if (mvec) load_n<true>(base, mstart + lane_off, mvalid, arr);
+                else load_n<false>(base, mstart + lane_off, mvalid, arr);
+            } else {
+                load_n<VEC>(base, start + lane_off, nvalid, arr);
+            }
+        });
         // stage the chunk in LDS in memory order, then gather this lane's (o,i)-row elements
         {
             size_t off = 0;
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(kTeam, IL_WAVES) void scan_interleaved_kernel(typen
                 if (base) {
                     const E *src = (const E *)(lds_in + off);
 #pragma unroll
-                    for (int e = 0; e < V; ++e) arr[e] = e < nvalid ? src[pe[e]] : (E)0;
+                    for (int e = 0; e < V; ++e) arr[e] = e < nvalid ? src[(sizeof(E) == 1 && bcast) ? pm[e] : pe[e]] : (E)0;
                 }
                 off += sizeof(E) * CH;
             });

@@ -43,13 +43,16 @@ __global__ __launch_bounds__(kSeqThreads) void gae_seq_kernel(GaeArgs a) {
     if (idx < a.O * a.I) {
         const i64 o = idx / a.I, i = idx - o * a.I;
         i64 j = (o * a.T + (a.T - 1)) * a.I + i;
+        // masks broadcast over the feature dims are read in place: element (o, t) for every i
+        const i64 ms = a.mask_bcast ? 1 : a.I;
+        i64 mj = a.mask_bcast ? o * a.T + (a.T - 1) : j;
         TC prev = (TC)0;
 #pragma unroll 4
-        for (i64 t = a.T - 1; t >= 0; --t, j -= a.I) {
+        for (i64 t = a.T - 1; t >= 0; --t, j -= a.I, mj -= ms) {
             const TG g = gt ? gt[j] : gs;
             const TG c = lgt ? lgt[j] : (gt ? ls * g : lgs);
-            const TG g_nt = g * (TG)(tm[j] ? 0 : 1);  // multiply, not select: inf*0 -> NaN as in the reference
-            const TG disc = c * (TG)(d[j] ? 0 : 1);
+            const TG g_nt = g * (TG)(tm[mj] ? 0 : 1);  // multiply, not select: inf*0 -> NaN as in the reference
+            const TG disc = c * (TG)(d[mj] ? 0 : 1);
             const TC delta = ((TC)r[j] + (TC)g_nt * (TC)nv[j]) - (TC)v[j];
             prev = delta + prev * (TC)disc;
             const TS as = (TS)prev;
@@ -85,11 +88,13 @@ __global__ __launch_bounds__(kSeqThreads) void td_lambda_seq_kernel(TdLambdaArgs
     if (idx >= a.O * a.I) return;
     const i64 o = idx / a.I, i = idx - o * a.I;
     i64 j = (o * a.T + (a.T - 1)) * a.I + i;
-    TC g = (TC)(nv[j] * (TS)(tm[j] ? 0 : 1));
+    const i64 ms = a.mask_bcast ? 1 : a.I;
+    i64 mj = a.mask_bcast ? o * a.T + (a.T - 1) : j;
+    TC g = (TC)(nv[j] * (TS)(tm[mj] ? 0 : 1));
 #pragma unroll 4
-    for (i64 t = a.T - 1; t >= 0; --t, j -= a.I) {
-        const TS dn = (TS)(d[j] ? 1 : 0), omd = (TS)(d[j] ? 0 : 1);
-        const TS nvm = nv[j] * (TS)(tm[j] ? 0 : 1);
+    for (i64 t = a.T - 1; t >= 0; --t, j -= a.I, mj -= ms) {
+        const TS dn = (TS)(d[mj] ? 1 : 0), omd = (TS)(d[mj] ? 0 : 1);
+        const TS nvm = nv[j] * (TS)(tm[mj] ? 0 : 1);
         const TG gm = gt ? gt[j] : gs;
         const TG lm = lt ? lt[j] : ls;
         const TG oml = (TG)1 - lm;
@@ -122,10 +127,12 @@ __global__ __launch_bounds__(kSeqThreads) void td_lambda_fixed_seq_kernel(TdLamb
     const TG lm = lt ? lt[jk] : (TG)a.lmbda;
     const TG oml = (TG)1 - lm;
     i64 j = (o * a.T + (a.T - 1)) * a.I + i;
-    TC g = (TC)(nv[j] * (TS)(tm[j] ? 0 : 1));
-    for (i64 t = a.T - 1; t >= k; --t, j -= a.I) {
-        const TS dn = (TS)(d[j] ? 1 : 0), omd = (TS)(d[j] ? 0 : 1);
-        const TS nvm = nv[j] * (TS)(tm[j] ? 0 : 1);
+    const i64 ms = a.mask_bcast ? 1 : a.I;
+    i64 mj = a.mask_bcast ? o * a.T + (a.T - 1) : j;
+    TC g = (TC)(nv[j] * (TS)(tm[mj] ? 0 : 1));
+    for (i64 t = a.T - 1; t >= k; --t, j -= a.I, mj -= ms) {
+        const TS dn = (TS)(d[mj] ? 1 : 0), omd = (TS)(d[mj] ? 0 : 1);
+        const TS nvm = nv[j] * (TS)(tm[mj] ? 0 : 1);
         g = g * (TC)omd + (TC)(nvm * dn);
         g = (TC)r[j] + (TC)gm * ((TC)oml * (TC)nvm + (TC)lm * g);
     }
@@ -160,13 +167,15 @@ __global__ __launch_bounds__(kSeqThreads) void vtrace_seq_kernel(VtraceArgs a) {
     if (idx >= a.O * a.I) return;
     const i64 o = idx / a.I, i = idx - o * a.I;
     i64 j = (o * a.T + (a.T - 1)) * a.I + i;
+    const i64 ms = a.mask_bcast ? 1 : a.I;
+    i64 mj = a.mask_bcast ? o * a.T + (a.T - 1) : j;
     TC x = (TC)0;
     TC vs_next = (TC)nv[j];
 #pragma unroll 2
-    for (i64 t = a.T - 1; t >= 0; --t, j -= a.I) {
+    for (i64 t = a.T - 1; t >= 0; --t, j -= a.I, mj -= ms) {
         const TG g = gt ? gt[j] : gs;
-        const TG dd = g * (TG)(d[j] ? 0 : 1);
-        const TG td = g * (TG)(tm[j] ? 0 : 1);
+        const TG dd = g * (TG)(d[mj] ? 0 : 1);
+        const TG td = g * (TG)(tm[mj] ? 0 : 1);
         const TS rho = exp_t(lp[j] - lmu[j]);
         const TS crho = clamp_max_nan(rho, rho_hi);
         const TS cc = clamp_max_nan(rho, c_hi);

@@ -225,6 +225,25 @@ def _mask(m: torch.Tensor, shape, device=None) -> torch.Tensor:
     return m.contiguous().view(torch.uint8)  # materialises stride-0 expanded masks (DoneTransform)
 
 
+def _masks(done: torch.Tensor, terminated: torch.Tensor, shape, time_dim: int, device, grads: bool):
+    """``(done_u8, terminated_u8, mask_bcast)`` for the native call.  Masks that are broadcast over every dim
+    after the time dim (stride 0 or extent 1: a per-env mask ``expand``ed over the agent dim, as
+    ``DoneTransform`` produces) are handed over as compact ``[*B, T]`` arrays and read in place by the kernels
+    (``mask_bcast = 1``); anything else is materialised in the canonical layout."""
+    nd = len(shape)
+    td = time_dim - nd if time_dim >= 0 else time_dim
+    n_feat = -td - 1
+    if n_feat > 0 and not grads and done.dtype == torch.bool and terminated.dtype == torch.bool:
+        feat = range(nd - n_feat, nd)
+        if math.prod(shape[d] for d in feat) > 1 and all(
+                tuple(m.shape) == tuple(shape) and all(m.stride(d) == 0 or shape[d] == 1 for d in feat)
+                for m in (done, terminated)):
+            index = (Ellipsis,) + (0,) * n_feat
+            compact = tuple(shape[:nd - n_feat])
+            return _mask(done[index], compact, device), _mask(terminated[index], compact, device), 1
+    return _mask(done, shape, device), _mask(terminated, shape, device), 0
+
+
 def _ptr(t: Optional[torch.Tensor]):
     # a plain int (or None) is what a c_void_p parameter converts fastest
     return t.data_ptr() if t is not None else None
@@ -284,6 +303,7 @@ class _GaeCall:
     gamma: float
     lmbda: float
     lg: float
+    mask_bcast: int = 0
 
 
 def _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim) -> _GaeCall:
@@ -318,11 +338,11 @@ def _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, term
         cdt = torch.promote_types(g_dt, lg_dt)
     if cdt not in _DT:
         raise NotImplementedError(f"gamma / lmbda dtype {cdt} is not supported (float32 / float64 only)")
+    d8, t8, bcast = _masks(done, terminated, shape, time_dim, dev, _needs_grad(state_value, next_state_value, reward))
     return _GaeCall(
         shape=shape, O=O, T=T, I=I, vdt=vdt, cdt=cdt, out_dtype=next_state_value.dtype,
         reward=_val(reward, vdt, dev), value=_val(state_value, vdt, dev), next_value=_val(next_state_value, vdt, dev),
-        done=_mask(done, shape, dev), terminated=_mask(terminated, shape, dev),
-        gamma_t=gamma_t, lg_t=lg_t, gamma=g_val, lmbda=l_val, lg=lg_val,
+        done=d8, terminated=t8, gamma_t=gamma_t, lg_t=lg_t, gamma=g_val, lmbda=l_val, lg=lg_val, mask_bcast=bcast,
     )
 
 
@@ -377,7 +397,7 @@ def _launch_gae(c: _GaeCall, want_stats: bool = False, algo: int = ALGO_AUTO, ou
     with _on(dev):
         rc = lib.trl_gae_fwd(
             _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.value), _ptr(c.next_value),
-            _ptr(c.done), _ptr(c.terminated), _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg,
+            _ptr(c.done), _ptr(c.terminated), c.mask_bcast, _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg,
             c.O, c.T, c.I, _ptr(adv), _ptr(vt), _ptr(stats), _ptr(ws), ws_bytes, algo)
     _extension.check(rc, lib)
     if c.out_dtype != c.vdt:
@@ -400,7 +420,7 @@ def _launch_gae_normalize(c: _GaeCall, eps: float, algo: int = ALGO_AUTO, out=No
     ws = _workspace(lib, dev, c.O, c.T, c.I)
     stats = torch.empty(3, dtype=torch.float64, device=dev) if want_stats else None
     head = (_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.value), _ptr(c.next_value),
-            _ptr(c.done), _ptr(c.terminated), _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg,
+            _ptr(c.done), _ptr(c.terminated), c.mask_bcast, _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg,
             c.O, c.T, c.I, _ptr(adv), _ptr(vt), float(eps), _ptr(stats), _ptr(ws), ws.numel())
     with _on(dev):
         if exchange is not None:
@@ -675,7 +695,7 @@ def prepare_gae_step(call: _GaeCall, eps: Optional[float] = None, *, normalize: 
     ws = _workspace(lib, dev, call.O, call.T, call.I)
     stats = torch.empty(3, dtype=torch.float64, device=dev) if want_stats else None
     head = (_stream(dev), _DT[call.vdt], _DT[call.cdt], _ptr(call.reward), _ptr(call.value), _ptr(call.next_value),
-            _ptr(call.done), _ptr(call.terminated), _ptr(call.gamma_t), _ptr(call.lg_t), call.gamma, call.lmbda, call.lg,
+            _ptr(call.done), _ptr(call.terminated), call.mask_bcast, _ptr(call.gamma_t), _ptr(call.lg_t), call.gamma, call.lmbda, call.lg,
             call.O, call.T, call.I, _ptr(adv), _ptr(vt))
     if normalize and exchange is not None:  # batch sharded over the exchange's ranks: still one C-ABI call
         calls = [(lib.trl_gae_normalize_xchg_fwd, head + (float(eps), _ptr(stats), _ptr(ws), ws.numel(), exchange.comm, algo))]
@@ -811,6 +831,7 @@ class _TdLambdaCall:
     gamma: float
     lmbda: float
     rolling: bool
+    mask_bcast: int = 0
 
 
 def _td_coef(x, done_shape, vdt, name):
@@ -855,9 +876,10 @@ def _prepare_td_lambda(gamma, lmbda, next_state_value, reward, done, terminated,
         g_t = g_t.to(device=dev, dtype=cdt).contiguous()
     if l_t is not None:
         l_t = l_t.to(device=dev, dtype=cdt).contiguous()
+    masks = _masks(done, terminated, shape, time_dim, dev, _needs_grad(next_state_value, reward))
     return _TdLambdaCall(shape=shape, O=O, T=T, I=I, vdt=vdt, cdt=cdt, reward=_val(reward, vdt, dev),
-                         next_value=_val(next_state_value, vdt, dev), done=_mask(done, shape, dev),
-                         terminated=_mask(terminated, shape, dev), gamma_t=g_t, lmbda_t=l_t, gamma=g_val,
+                         next_value=_val(next_state_value, vdt, dev), done=masks[0],
+                         terminated=masks[1], mask_bcast=masks[2], gamma_t=g_t, lmbda_t=l_t, gamma=g_val,
                          lmbda=l_val, rolling=bool(rolling_gamma))
 
 
@@ -872,7 +894,7 @@ def _launch_td_lambda(c: _TdLambdaCall, out_dtype, algo: int = ALGO_AUTO) -> tor
     with _on(dev):
         rc = lib.trl_td_lambda_fwd(
             _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.next_value), _ptr(c.done), _ptr(c.terminated),
-            _ptr(c.gamma_t), _ptr(c.lmbda_t), c.gamma, c.lmbda, 1 if c.rolling else 0, c.O, c.T, c.I, _ptr(out),
+            c.mask_bcast, _ptr(c.gamma_t), _ptr(c.lmbda_t), c.gamma, c.lmbda, 1 if c.rolling else 0, c.O, c.T, c.I, _ptr(out),
             _ptr(ws), ws.numel() if ws is not None else 0, algo)
     _extension.check(rc, lib)
     return out if out_dtype == c.vdt else out.to(out_dtype)
@@ -1018,6 +1040,7 @@ class _VtraceCall:
     gamma: float
     rho_thresh: float
     c_thresh: float
+    mask_bcast: int = 0
 
 
 def _thresh(x) -> float:
@@ -1052,10 +1075,11 @@ def _prepare_vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward
     def bc(t):
         return t if tuple(t.shape) == shape else _expand_coef(t, shape, time_dim)
 
+    masks = _masks(done, terminated, shape, time_dim, dev, _needs_grad(log_pi, log_mu, state_value, next_state_value, reward))
     return _VtraceCall(shape=shape, O=O, T=T, I=I, vdt=vdt, cdt=cdt, log_pi=_val(bc(log_pi), vdt, dev),
                        log_mu=_val(bc(log_mu), vdt, dev), value=_val(state_value, vdt, dev),
                        next_value=_val(next_state_value, vdt, dev), reward=_val(reward, vdt, dev),
-                       done=_mask(done, shape, dev), terminated=_mask(terminated, shape, dev), gamma_t=gamma_t,
+                       done=masks[0], terminated=masks[1], mask_bcast=masks[2], gamma_t=gamma_t,
                        gamma=g_val, rho_thresh=_thresh(rho_thresh), c_thresh=_thresh(c_thresh))
 
 
@@ -1072,7 +1096,7 @@ def _launch_vtrace(c: _VtraceCall, algo: int = ALGO_AUTO):
     with _on(dev):
         rc = lib.trl_vtrace_fwd(
             _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.log_pi), _ptr(c.log_mu), _ptr(c.value), _ptr(c.next_value),
-            _ptr(c.reward), _ptr(c.done), _ptr(c.terminated), _ptr(c.gamma_t), c.gamma, c.rho_thresh, c.c_thresh,
+            _ptr(c.reward), _ptr(c.done), _ptr(c.terminated), c.mask_bcast, _ptr(c.gamma_t), c.gamma, c.rho_thresh, c.c_thresh,
             c.O, c.T, c.I, _ptr(adv), _ptr(vs), _ptr(ws), ws.numel() if ws is not None else 0, algo)
     _extension.check(rc, lib)
     return adv, vs
