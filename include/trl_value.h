@@ -187,6 +187,16 @@ int trl_moments(void *stream, int dtype, const void *x, int64_t n,
                 double *stats, void *workspace, size_t workspace_bytes);
 
 /*
+ * trl_moments + trl_normalize in one call (out-of-place or in place): `(x - x.mean()) / x.std().clamp_min(eps)`,
+ * _standardize(x) without exclude_dims (torchrl/_utils.py:901-912) -- what PPO applies to every minibatch of
+ * advantages (torchrl/objectives/ppo.py:688, 975, 1282).  n <= 65536 (a minibatch): ONE single-block launch,
+ * no workspace needed; larger: moments -> reduce -> scale pass, needs `workspace` of
+ * trl_workspace_bytes(n, 1, 1).  stats (optional, device double[3]) receives {N, sum, sumsq}.
+ */
+int trl_standardize(void *stream, int dtype, const void *x, int64_t n, double eps, void *out, double *stats,
+                    void *workspace, size_t workspace_bytes);
+
+/*
  * Per-group statistics and normalisation.
  * Replaces: _standardize(input, exclude_dims) (torchrl/_utils.py:875-936; PPO's advantage
  *           normalisation, torchrl/objectives/ppo.py:688, 975, 1282): mean / unbiased std over the
@@ -205,6 +215,9 @@ int trl_moments_grouped(void *stream, int dtype, const void *x, int64_t outer, i
                         double *stats, void *workspace, size_t workspace_bytes);
 int trl_normalize_grouped(void *stream, int dtype, const void *x, int64_t outer, int64_t G, int64_t inner,
                           const double *stats, double eps, void *out);
+/* both of the above in one call (single GPU); stats: device double[G*3], filled on the way */
+int trl_standardize_grouped(void *stream, int dtype, const void *x, int64_t outer, int64_t G, int64_t inner,
+                            double eps, void *out, double *stats, void *workspace, size_t workspace_bytes);
 
 /*
  * Cross-GPU sum of the moments -- the one collective of the path when the env dimension is sharded

@@ -110,3 +110,19 @@ def test_hip_matches_oracle_larger_shapes(shape, ex, dtype):
     torch.testing.assert_close(out.cpu(), want, equal_nan=True, **tol(dtype))
     # the device statistics are reproducible run to run (fixed reduction order)
     assert torch.equal(out, _standardize(x.to("cuda:0"), ex, eps=1e-6)) or torch.isnan(out).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 1000, 65536, 65537, 300000], ids=lambda n: f"n{n}")
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_hip_ungrouped_small_and_large(n, dtype):
+    """No excluded dims: one single-block launch up to 65536 elements (a PPO minibatch), moments -> reduce ->
+    scale pass above; n = 1 gives NaN as torch's unbiased std does."""
+    from torchrl_amd._utils import _standardize
+    from torchrl_amd.objectives.value import functional as F
+
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(n, generator=g, dtype=torch.float64) * 2 - 0.3).to(dtype)
+    out = _standardize(x.to("cuda:0"), eps=1e-6)
+    assert F.last_kernel() == ("standardize_small" if n <= 65536 else "normalize")
+    torch.testing.assert_close(out.cpu(), O.standardize(x, (), 1e-6), equal_nan=True, **tol(dtype))

@@ -54,6 +54,8 @@ _PROTOTYPES = {
                               _i64, _i64, _i64, _vp, _vp, _vp, _sz, _int]),
     "trl_normalize": (_int, [_vp, _int, _vp, _i64, _vp, _dbl, _vp]),
     "trl_moments": (_int, [_vp, _int, _vp, _i64, _vp, _vp, _sz]),
+    "trl_standardize": (_int, [_vp, _int, _vp, _i64, _dbl, _vp, _vp, _vp, _sz]),
+    "trl_standardize_grouped": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _dbl, _vp, _vp, _vp, _sz]),
     "trl_grouped_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "trl_moments_grouped": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp, _vp, _sz]),
     "trl_normalize_grouped": (_int, [_vp, _int, _vp, _i64, _i64, _i64, _vp, _dbl, _vp]),

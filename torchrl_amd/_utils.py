@@ -17,6 +17,8 @@ from .objectives.value import functional as F
 
 __all__ = ["_standardize"]
 
+_SCRATCH = {}  # (device, stream) -> scratch buffer (per-group moments + partials)
+
 
 def _grouped_pattern(shape, exclude_dims):
     """(outer, G, inner, permutation or None): excluded dims that are adjacent merge into one group
@@ -74,17 +76,26 @@ def _standardize(input: Tensor, exclude_dims: Tuple[int] = (), mean: Optional[Te
     x = input.detach()
     x = x.contiguous() if perm is None else x.permute(perm).contiguous()
     dev = x.device
-    need = lib.trl_grouped_workspace_bytes(outer, G, inner)
-    ws = torch.empty(need, dtype=torch.uint8, device=dev)
-    stats = torch.empty(G * 3, dtype=torch.float64, device=dev)
+    head = ((G * 24 + 255) // 256) * 256  # the per-group moments live at the head of the scratch buffer
+    need = head + lib.trl_grouped_workspace_bytes(outer, G, inner)
+    key = (dev.index, F._stream(dev))
+    ws = _SCRATCH.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _SCRATCH[key] = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=dev)
+    stats = ws[:G * 24].view(torch.float64)
+    wsp, wsn = ws.data_ptr() + head, ws.numel() - head
     out = torch.empty_like(x)
-    with torch.cuda.device(dev):
-        _extension.check(lib.trl_moments_grouped(F._stream(dev), F._DT[x.dtype], F._ptr(x), outer, G, inner, F._ptr(stats),
-                                                 F._ptr(ws), ws.numel()), lib)
-        if group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+    sharded = group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1
+    with F._on(dev):
+        if not sharded:  # one C-ABI call: moments -> per-group reduce -> scale pass
+            _extension.check(lib.trl_standardize_grouped(F._stream(dev), F._DT[x.dtype], F._ptr(x), outer, G, inner, float(eps),
+                                                         F._ptr(out), F._ptr(stats), wsp, wsn), lib)
+        else:
+            _extension.check(lib.trl_moments_grouped(F._stream(dev), F._DT[x.dtype], F._ptr(x), outer, G, inner, F._ptr(stats),
+                                                     wsp, wsn), lib)
             torch.distributed.all_reduce(stats, group=group)
-        _extension.check(lib.trl_normalize_grouped(F._stream(dev), F._DT[x.dtype], F._ptr(x), outer, G, inner, F._ptr(stats),
-                                                   float(eps), F._ptr(out)), lib)
+            _extension.check(lib.trl_normalize_grouped(F._stream(dev), F._DT[x.dtype], F._ptr(x), outer, G, inner, F._ptr(stats),
+                                                       float(eps), F._ptr(out)), lib)
     if perm is not None:
         inv = [0] * len(perm)
         for k, d in enumerate(perm):

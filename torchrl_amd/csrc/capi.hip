@@ -259,6 +259,30 @@ int trl_normalize(void *stream, int dtype, const void *x, int64_t n, const doubl
     return TRL_OK;
 }
 
+int trl_standardize(void *stream, int dtype, const void *x, int64_t n, double eps, void *out, double *stats,
+                    void *workspace, size_t workspace_bytes) {
+    if (!dtype_ok(dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_standardize: bad dtype");
+    if (n <= 0 || !x || !out) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_standardize: null pointer or n <= 0");
+    if (standardize_small_ok(n)) {
+        launch_standardize_small((hipStream_t)stream, dtype, x, n, eps, out, stats);
+        if (int rc = check_launch("trl_standardize")) return rc;
+        g_kernel = "standardize_small";
+        return TRL_OK;
+    }
+    if (!workspace || workspace_bytes < trl_workspace_bytes(n, 1, 1) || ((uintptr_t)workspace & 7))
+        return fail(TRL_ERR_WORKSPACE, "trl_standardize: workspace is %zu bytes, need %zu (8-byte aligned)", workspace_bytes,
+                    trl_workspace_bytes(n, 1, 1));
+    double *st = stats ? stats : (double *)((char *)workspace + kWsStatsOffset);
+    if (int rc = trl_moments(stream, dtype, x, n, st, workspace, workspace_bytes)) return rc;
+    return trl_normalize(stream, dtype, x, n, st, eps, out);
+}
+
+int trl_standardize_grouped(void *stream, int dtype, const void *x, int64_t outer, int64_t G, int64_t inner, double eps, void *out,
+                            double *stats, void *workspace, size_t workspace_bytes) {
+    if (int rc = trl_moments_grouped(stream, dtype, x, outer, G, inner, stats, workspace, workspace_bytes)) return rc;
+    return trl_normalize_grouped(stream, dtype, x, outer, G, inner, stats, eps, out);
+}
+
 size_t trl_grouped_workspace_bytes(int64_t outer, int64_t G, int64_t inner) {
     if (outer <= 0 || G <= 0 || inner <= 0) return 0;
     return (size_t)G * (size_t)grouped_blocks_per_group(outer, G, inner) * 2 * sizeof(double) + 256;

@@ -135,6 +135,8 @@ int launch_reduce_partials(hipStream_t s, const double *partials, i64 npartials,
 int launch_moments(hipStream_t s, int dt, const void *x, i64 n, double *partials, i64 *npartials);
 i64 moments_max_partials(i64 n);
 int launch_normalize(hipStream_t s, int dt, const void *x, i64 n, const double *stats, double eps, void *out);
+bool standardize_small_ok(i64 n);
+int launch_standardize_small(hipStream_t s, int dt, const void *x, i64 n, double eps, void *out, double *stats_out);
 // grouped statistics (x seen as (outer, G, inner); group g = (f / inner) % G); status 2 = G too large
 i64 grouped_blocks_per_group(i64 outer, i64 G, i64 inner);
 int launch_moments_grouped(hipStream_t s, int dt, const void *x, i64 outer, i64 G, i64 inner, double *partials, double *stats);

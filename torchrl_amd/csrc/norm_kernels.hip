@@ -210,6 +210,32 @@ __global__ __launch_bounds__(kRedThreads) void normalize_grouped_by_group_kernel
     }
 }
 
+// Small tensors (a PPO minibatch of advantages): moments and scale pass in ONE single-block launch;
+// the second pass re-reads x from L2.  Same fixed reduction order every run.
+constexpr int kSmallThreads = 1024;
+template <typename TS>
+__global__ __launch_bounds__(kSmallThreads) void standardize_small_kernel(const TS *__restrict__ x, i64 n, double eps,
+                                                                          TS *__restrict__ out, double *__restrict__ stats_out) {
+    __shared__ double red[2 * kSmallThreads / kWave];
+    __shared__ double bc[2];
+    double s = 0.0, ss = 0.0;
+    for (i64 k = threadIdx.x; k < n; k += kSmallThreads) {
+        const double xv = (double)x[k];
+        s += xv;
+        ss += xv * xv;
+    }
+    block_sum2<kSmallThreads>(s, ss, red);
+    if (threadIdx.x == 0) {
+        bc[0] = s;
+        bc[1] = ss;
+        if (stats_out) { stats_out[0] = (double)n; stats_out[1] = s; stats_out[2] = ss; }
+    }
+    __syncthreads();
+    TS mean_s, std_s;
+    mean_std<TS>((double)n, bc[0], bc[1], eps, mean_s, std_s);
+    for (i64 k = threadIdx.x; k < n; k += kSmallThreads) out[k] = (x[k] - mean_s) / std_s;
+}
+
 inline i64 stream_blocks(i64 n, int per_thread) {
     i64 nb = (n + (i64)kRedThreads * per_thread - 1) / ((i64)kRedThreads * per_thread);
     if (nb < 1) nb = 1;
@@ -304,5 +330,16 @@ int launch_normalize_grouped(hipStream_t s, int dt, const void *x, i64 outer, i6
             hipLaunchKernelGGL((normalize_grouped_by_group_kernel<double>), grid, dim3(kRedThreads), 0, s, (const double *)x, outer, G,
                                inner, stats, eps, (double *)out);
     }
+    return 0;
+}
+
+// ---- one-call standardisation ---------------------------------------------------------------------
+bool standardize_small_ok(i64 n) { return n <= 65536; }
+
+int launch_standardize_small(hipStream_t s, int dt, const void *x, i64 n, double eps, void *out, double *stats_out) {
+    if (dt == 0)
+        hipLaunchKernelGGL((standardize_small_kernel<float>), dim3(1), dim3(kSmallThreads), 0, s, (const float *)x, n, eps, (float *)out, stats_out);
+    else
+        hipLaunchKernelGGL((standardize_small_kernel<double>), dim3(1), dim3(kSmallThreads), 0, s, (const double *)x, n, eps, (double *)out, stats_out);
     return 0;
 }

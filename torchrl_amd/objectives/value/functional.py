@@ -804,11 +804,26 @@ def standardize(x: torch.Tensor, eps: float, group=None, distributed: bool = Fal
     (or an explicit process ``group``) the fp64 moments are all-reduced first -- one 24-byte RCCL
     all-reduce -- so every rank normalises with the global statistics of the sharded batch."""
     xc = x.detach().contiguous()
-    st = moments(xc)
-    if (distributed or group is not None) and torch.distributed.is_initialized():
-        if torch.distributed.get_world_size(group) > 1:
-            torch.distributed.all_reduce(st, group=group)
-    return normalize_(xc, st, eps, out=torch.empty_like(xc))
+    if (distributed or group is not None) and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+        st = moments(xc)
+        torch.distributed.all_reduce(st, group=group)
+        return normalize_(xc, st, eps, out=torch.empty_like(xc))
+    # single GPU: one C-ABI call (one single-block launch up to 65536 elements -- a PPO minibatch)
+    lib = _extension.get_lib()
+    _require_hip(xc)
+    if xc.dtype not in _DT:
+        raise NotImplementedError(f"standardize: dtype {xc.dtype} unsupported")
+    n = xc.numel()
+    out = torch.empty_like(xc)
+    if n == 0:
+        return out
+    dev = xc.device
+    ws = _workspace(lib, dev, n, 1, 1) if n > 65536 else None
+    with _on(dev):
+        rc = lib.trl_standardize(_stream(dev), _DT[xc.dtype], _ptr(xc), n, float(eps), _ptr(out), None, _ptr(ws),
+                                 ws.numel() if ws is not None else 0)
+    _extension.check(rc, lib)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
