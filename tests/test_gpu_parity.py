@@ -436,3 +436,41 @@ def test_broadcast_masks_read_in_place(shape, time_dim, dtype):
     if shape[len(shape) + td] <= 50:
         got = F.td_lambda_return_estimate(cu(gam), 0.9, cu(nv), cu(r), dd, tt, rolling_gamma=False, time_dim=time_dim)
         check(got, O.td_lambda(gam, 0.9, nv, r, done, term, rolling_gamma=False, time_dim=time_dim), True)
+
+
+LONG_IL = [((16, 400, 5), -2), ((3, 2000, 3, 2), 1), ((64, 1000, 5, 1), -3), ((5, 300, 4), -2)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape,time_dim", LONG_IL, ids=["x".join(map(str, s)) for s, _ in LONG_IL])
+@pytest.mark.parametrize("bcast", [False, True], ids=["full_masks", "bcast_masks"])
+def test_long_rows_with_few_features_take_the_time_major_route(shape, time_dim, dtype, bcast):
+    """I < 32 and T * I beyond one chunk: re-laid out time-major onto the I == 1 kernels (instead of the
+    uncoalesced SEQ walk); all three estimators and the normalised GAE, SCAN-family tolerance."""
+    r, v, nv, done, term, gam, lp, lm = _rand_inputs(shape, dtype, seed=31, p_term=0.01, p_trunc=0.01)
+    if bcast:
+        td = time_dim if time_dim < 0 else time_dim - len(shape)
+        idx = (Ellipsis,) + (slice(0, 1),) * (-td - 1)
+        done, term = done[idx].expand(shape), term[idx].expand(shape)
+    oadv, ovt = O.gae(gam, 0.9, v, nv, r, done, term, time_dim=time_dim)
+    oret = O.td_lambda(0.97, 0.9, nv, r, done, term, time_dim=time_dim)
+    ova, ovs = O.vtrace(gam, lp, lm, v, nv, r, done, term, time_dim=time_dim)
+    dd, tt = (cu(done), cu(term)) if not bcast else (cu(done[idx]).expand(shape), cu(term[idx]).expand(shape))
+    adv, vt = F.generalized_advantage_estimate(cu(gam), 0.9, cu(v), cu(nv), cu(r), dd, tt, time_dim=time_dim)
+    assert "scan" in F.last_kernel() and adv.is_contiguous()
+    check(adv, oadv, False, done)
+    check(vt, ovt, False, done)
+    check(F.td_lambda_return_estimate(0.97, 0.9, cu(nv), cu(r), dd, tt, time_dim=time_dim), oret, False)
+    assert "scan" in F.last_kernel()
+    va, vs = F.vtrace_advantage_estimate(cu(gam), cu(lp), cu(lm), cu(v), cu(nv), cu(r), dd, tt, time_dim=time_dim)
+    assert "scan" in F.last_kernel()
+    check(va, ova, False)
+    check(vs, ovs, False)
+    nadv, vt2 = F.gae_normalized(cu(gam), 0.9, cu(v), cu(nv), cu(r), dd, tt, time_dim=time_dim)
+    torch.testing.assert_close(nadv.cpu(), O.normalize(oadv, 1e-4), rtol=2e-5, atol=2e-5)
+    check(vt2, ovt, False, done)
+    # the exact family is still there on request
+    gcall = F._prepare_gae(cu(gam), 0.9, cu(v), cu(nv), cu(r), dd, tt, time_dim)
+    adv_seq, _, _ = F._launch_gae(gcall, algo=SEQ)
+    assert F.last_kernel() == "gae_seq"
+    check(adv_seq, oadv, True)

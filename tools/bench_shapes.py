@@ -27,4 +27,15 @@ for spec in sys.argv[1:]:
     torch.cuda.synchronize()
     us = a.elapsed_time(b) / 200 * 1e3
     nb = O * T * I * (5 * r.element_size() + 2)
-    print(f"{spec:18s} {us:8.2f} us  {nb / us / 1e3:8.1f} GB/s  [{F.last_kernel()}]", flush=True)
+    kern = F.last_kernel()
+    fn = lambda: F.generalized_advantage_estimate(0.9, 0.9, v, nv, r, done, term)
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(50):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    us_entry = a.elapsed_time(b) / 50 * 1e3
+    print(f"{spec:18s} bound call {us:8.2f} us  {nb / us / 1e3:8.1f} GB/s  [{kern}]   entry point {us_entry:8.2f} us  [{F.last_kernel()}]", flush=True)
