@@ -57,7 +57,9 @@ enum {
     TRL_ALGO_SCAN = 2, /* wavefront scan of affine maps over time (I == 1): tolerance-level parity,
                           bit-exact at done boundaries */
     TRL_ALGO_FUSED = 3 /* trl_gae_normalize_fwd only: single persistent launch, advantages kept in
-                          registers across an in-launch all-gather of the fp64 moments */
+                          registers across an in-launch all-gather of the fp64 moments */,
+    TRL_ALGO_LOCKSTEP = 4 /* 2 <= I <= 8 feature elements per step, any T: a lane owns one time step, the I
+                          recurrences are scanned in lock step (no LDS transpose); same parity as SCAN */
 };
 
 int trl_abi_version(void);

@@ -12,7 +12,7 @@ from torchrl_amd.objectives.value import functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-SEQ, SCAN = F.ALGO_SEQ, F.ALGO_SCAN
+SEQ, SCAN, LOCKSTEP = F.ALGO_SEQ, F.ALGO_SCAN, F.ALGO_LOCKSTEP
 
 
 def tol(dtype):
@@ -37,7 +37,10 @@ def check(out, ref, exact, done=None):
 def algos(call):
     """SEQ always; SCAN when the family supports the shape (I == 1, or whole outer rows fit a chunk)."""
     chunk = 256 * (4 if call.vdt == torch.float32 else 2)
-    return [SEQ, SCAN] if (call.I == 1 or call.T * call.I <= chunk) else [SEQ]
+    out = [SEQ, SCAN] if (call.I == 1 or call.T * call.I <= chunk) else [SEQ]
+    if 2 <= call.I <= 8 and not (call.vdt == torch.float32 and call.cdt == torch.float64):
+        out.append(LOCKSTEP)  # a lane per time step, the I recurrences in lock step: any T
+    return out
 
 
 @pytest.mark.parametrize("meta", G.cases("gae"), ids=G.ids("gae"))
@@ -438,15 +441,17 @@ def test_broadcast_masks_read_in_place(shape, time_dim, dtype):
         check(got, O.td_lambda(gam, 0.9, nv, r, done, term, rolling_gamma=False, time_dim=time_dim), True)
 
 
-LONG_IL = [((16, 400, 5), -2), ((3, 2000, 3, 2), 1), ((64, 1000, 5, 1), -3), ((5, 300, 4), -2)]
+LONG_IL = [((16, 400, 5), -2), ((3, 2000, 3, 2), 1), ((64, 1000, 5, 1), -3), ((5, 300, 4), -2), ((7, 257, 2), -2), ((2, 5000, 8), -2),
+           ((300, 256, 7), -2), ((40, 700, 12), -2)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("shape,time_dim", LONG_IL, ids=["x".join(map(str, s)) for s, _ in LONG_IL])
 @pytest.mark.parametrize("bcast", [False, True], ids=["full_masks", "bcast_masks"])
-def test_long_rows_with_few_features_take_the_time_major_route(shape, time_dim, dtype, bcast):
-    """I < 32 and T * I beyond one chunk: re-laid out time-major onto the I == 1 kernels (instead of the
-    uncoalesced SEQ walk); all three estimators and the normalised GAE, SCAN-family tolerance."""
+def test_long_rows_with_few_features(shape, time_dim, dtype, bcast):
+    """T * I beyond one chunk of the LDS-transposing kernel: 2 <= I <= 8 takes the lock-step kernels (a lane per
+    time step, chunk loop with I carries), 8 < I < 32 with few rows is re-laid out time-major onto the I == 1
+    kernels -- never the uncoalesced SEQ walk; all three estimators and the normalised GAE, SCAN-family tolerance."""
     r, v, nv, done, term, gam, lp, lm = _rand_inputs(shape, dtype, seed=31, p_term=0.01, p_trunc=0.01)
     if bcast:
         td = time_dim if time_dim < 0 else time_dim - len(shape)

@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torchrl_amd.objectives.value import functional as F  # noqa: E402
 
 dev = torch.device("cuda:0")
+ALGO = int(os.environ.get("TRL_ALGO", "0"))  # 0 auto, 1 seq, 2 scan, 4 lockstep
 for spec in sys.argv[1:]:
     dt = torch.float64 if spec.endswith("d") else torch.float32
     O, T, I = (int(x) for x in spec.rstrip("d").split("x"))
@@ -15,7 +16,7 @@ for spec in sys.argv[1:]:
     term = torch.rand(shape, device=dev) < 0.01
     done = term | (torch.rand(shape, device=dev) < 0.01)
     call = F._prepare_gae(0.9, 0.9, v, nv, r, done, term, -2)
-    st = F.prepare_gae_step(call, normalize=False)
+    st = F.prepare_gae_step(call, normalize=False, algo=ALGO)
     for _ in range(10):
         st.run()
     torch.cuda.synchronize()

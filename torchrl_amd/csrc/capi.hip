@@ -65,6 +65,18 @@ void *lb_region(void *workspace, size_t workspace_bytes, i64 O, i64 T, i64 I, si
 
 }  // namespace
 
+// I > 1 with whole outer rows inside one chunk: both the LDS-transposing SCAN kernel and the lock-step kernels
+// apply.  Measured (fp32 / fp64, T = 32..100, I = 2..8): the transposing kernel wins when its chunk is full
+// (R*T*I >= 95 % of 256*V elements: [8192x100x5] 23.0 vs 23.3 us, [8192x32x8] 11.4 vs 14.8), the lock-step
+// kernels otherwise ([8192x100x3] 15.5 vs 19.5, [8192x100x8] 38 vs 61).
+static bool prefer_lockstep(int val_dtype, int coef_dtype, int64_t T, int64_t I) {
+    if (I < 2 || I > 8 || (val_dtype == TRL_F32 && coef_dtype == TRL_F64)) return false;
+    const int64_t chunk = 256 * (val_dtype == TRL_F32 ? 4 : 2);
+    if (T * I > chunk) return true;
+    const int64_t R = chunk / (T * I);
+    return R * T * I * 100 < chunk * 95;
+}
+
 // error reporting for the other translation units' entry points (xchg_kernels.hip)
 int trl_internal_fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -114,14 +126,20 @@ int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward,
               O, T, I, advantage, value_target, stats ? (double *)((char *)workspace + kWsPartialsOffset) : nullptr,
               (mask_bcast && I > 1) ? 1 : 0};
     hipStream_t s = (hipStream_t)stream;
-    if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ)
+    if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ && algo != TRL_ALGO_LOCKSTEP)
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: unknown algo %d", algo);
     LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
     size_t lb_bytes = 0;
     void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
-    if (algo != TRL_ALGO_SEQ) res = launch_gae_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
+    if (algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I)) res = launch_gae_lockstep(s, val_dtype, coef_dtype, a);
+    if (res.status == TRL_ERR_UNSUPPORTED && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN))
+        res = launch_gae_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
         return fail(TRL_ERR_UNSUPPORTED, "trl_gae_fwd: SCAN family does not support this shape (needs I == 1)");
+    if (res.status == TRL_ERR_UNSUPPORTED && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_LOCKSTEP))
+        res = launch_gae_lockstep(s, val_dtype, coef_dtype, a);
+    if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_LOCKSTEP)
+        return fail(TRL_ERR_UNSUPPORTED, "trl_gae_fwd: LOCKSTEP family needs 2 <= I <= 8 (and not fp32 values with fp64 coefficients)");
     if (res.status == TRL_ERR_UNSUPPORTED) res = launch_gae_seq(s, val_dtype, coef_dtype, a);
     if (res.status != 0) return fail(res.status, "trl_gae_fwd: launch rejected (grid too large?)");
     if (int rc = check_launch("trl_gae_fwd")) return rc;
@@ -148,13 +166,20 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype, const void *r
                    (mask_bcast && I > 1) ? 1 : 0};
     hipStream_t s = (hipStream_t)stream;
     LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
-    if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ)
+    if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ && algo != TRL_ALGO_LOCKSTEP)
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td_lambda_fwd: unknown algo %d", algo);
     size_t lb_bytes = 0;
     void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
-    if (rolling_gamma && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN)) res = launch_td_lambda_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
+    if (rolling_gamma && algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I))
+        res = launch_td_lambda_lockstep(s, val_dtype, coef_dtype, a);
+    if (res.status == TRL_ERR_UNSUPPORTED && rolling_gamma && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN))
+        res = launch_td_lambda_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
         return fail(TRL_ERR_UNSUPPORTED, "trl_td_lambda_fwd: SCAN family does not support this case (needs I == 1, rolling gamma)");
+    if (res.status == TRL_ERR_UNSUPPORTED && rolling_gamma && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_LOCKSTEP))
+        res = launch_td_lambda_lockstep(s, val_dtype, coef_dtype, a);
+    if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_LOCKSTEP)
+        return fail(TRL_ERR_UNSUPPORTED, "trl_td_lambda_fwd: LOCKSTEP family needs 2 <= I <= 8 (not fp32 values with fp64 coefficients), rolling gamma");
     if (res.status == TRL_ERR_UNSUPPORTED) res = launch_td_lambda_seq(s, val_dtype, coef_dtype, a, rolling_gamma);
     if (res.status != 0) return fail(res.status, "trl_td_lambda_fwd: launch rejected (grid too large?)");
     if (int rc = check_launch("trl_td_lambda_fwd")) return rc;
@@ -175,13 +200,19 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_
                  gamma, rho_thresh, c_thresh, O, T, I, advantage, vs, (mask_bcast && I > 1) ? 1 : 0};
     hipStream_t s = (hipStream_t)stream;
     LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
-    if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ)
+    if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ && algo != TRL_ALGO_LOCKSTEP)
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_fwd: unknown algo %d", algo);
     size_t lb_bytes = 0;
     void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
-    if (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN) res = launch_vtrace_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
+    if (algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I)) res = launch_vtrace_lockstep(s, val_dtype, coef_dtype, a);
+    if (res.status == TRL_ERR_UNSUPPORTED && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN))
+        res = launch_vtrace_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
         return fail(TRL_ERR_UNSUPPORTED, "trl_vtrace_fwd: SCAN family does not support this shape (needs I == 1)");
+    if (res.status == TRL_ERR_UNSUPPORTED && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_LOCKSTEP))
+        res = launch_vtrace_lockstep(s, val_dtype, coef_dtype, a);
+    if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_LOCKSTEP)
+        return fail(TRL_ERR_UNSUPPORTED, "trl_vtrace_fwd: LOCKSTEP family needs 2 <= I <= 8 (and not fp32 values with fp64 coefficients)");
     if (res.status == TRL_ERR_UNSUPPORTED) res = launch_vtrace_seq(s, val_dtype, coef_dtype, a);
     if (res.status != 0) return fail(res.status, "trl_vtrace_fwd: launch rejected (grid too large?)");
     if (int rc = check_launch("trl_vtrace_fwd")) return rc;

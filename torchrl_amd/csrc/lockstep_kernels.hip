@@ -1,0 +1,243 @@
+// Lock-step scan kernels for a FEW feature elements per time step (2 <= I <= 8), any T.
+//
+// Element (o, t, i) sits at (o*T + t)*I + i: the I scans of an outer row are interleaved in memory (multi-agent
+// rollouts [E, T, A, 1], torchrl's MAPPO / IPPO configs).  Here a LANE owns one time step and its I feature elements
+// (I is a template parameter: registers, no indexing), so
+//   * a wave reads / writes 64*I consecutive elements per tensor -- HBM traffic is the algorithmic minimum, no LDS
+//     transpose (the LDS-transposing kernel of scan_kernels.hip needs T*I <= one chunk and is occupancy-bound);
+//   * the I recurrences advance in LOCK STEP: the suffix scan over the lanes (DPP row shifts, two cross-row shuffles,
+//     wave aggregates through LDS) composes I independent affine maps per move, and the step that follows (t, i)
+//     is always element i of the next lane;
+//   * masks that are shared by the I elements of a step (mask_bcast) are one byte per lane.
+// Short outer rows (T <= 256): a chunk is R = 256 / T whole rows, blocks walk chunks grid-stride.  Long rows: a block
+// owns outer rows and walks each row's 256-step chunks from the end, the I carries (and V-trace's I next
+// state_values) in registers.  Same arithmetic contract as the SCAN family: every lane replays its step with the
+// reference's exact expression from its carry-in; row ends are hard resets, `done` a multiplication by zero.
+#include "scan_core.h"
+
+namespace {
+
+using namespace scan;
+
+constexpr int kLsThreads = 256;
+
+struct LsGeom {
+    i64 O, T;
+    int rows_per_chunk;  // short rows: whole outer rows per chunk; 0: long rows
+    i64 nchunks;         // short rows: chunks in total; long rows: chunks per row
+};
+
+template <class Op>
+struct LsShared {
+    typename Op::TC a[2][kWaves][Op::V], b[2][kWaves][Op::V];
+    int h[2][kWaves][Op::V];
+    typename Op::TS v0[2][kWaves][Op::V];
+};
+
+// One chunk: lane = one time step (valid or not), op prepared with the step's I elements.
+// Xc / Xv (in/out, block-uniform): x / state_value of the step that follows the chunk, per feature element; on exit those
+// of the chunk's first step.
+template <class Op, class Emit>
+__device__ __forceinline__ void ls_chunk(const Op &op, LsShared<Op> &sh, int buf, bool valid, bool row_end,
+                                         typename Op::TC (&Xc)[Op::V], typename Op::TS (&Xv)[Op::V], Emit &&emit) {
+    typedef typename Op::TC TC;
+    typedef typename Op::TS TS;
+    constexpr int NI = Op::V;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    const int lir = lane & 15, row = lane >> 4;
+
+    Aff<TC> S[NI];
+#pragma unroll
+    for (int e = 0; e < NI; ++e) {
+        if (!valid) S[e] = Aff<TC>{(TC)1, (TC)0, 0};
+        else if (row_end) S[e] = Aff<TC>{(TC)0, op.step(e, op.init(e)), 1};
+        else { S[e].h = 0; op.affine(e, S[e].a, S[e].b); }
+    }
+    // inclusive suffix scan over the wave, I maps per move
+#define TRL_LS_STEP(OFF)                                                                                     \
+    _Pragma("unroll") for (int e = 0; e < NI; ++e) {                                                         \
+        Aff<TC> p{dpp_mov<0x100 + OFF>(S[e].a), dpp_mov<0x100 + OFF>(S[e].b), dpp_mov<0x100 + OFF>(S[e].h)}; \
+        if (lir + OFF < 16) S[e] = compose(S[e], p);                                                         \
+    }
+    TRL_LS_STEP(1)
+    TRL_LS_STEP(2)
+    TRL_LS_STEP(4)
+    TRL_LS_STEP(8)
+#undef TRL_LS_STEP
+#pragma unroll
+    for (int e = 0; e < NI; ++e) {
+        Aff<TC> p{__shfl(S[e].a, (row + 1) << 4, kWave), __shfl(S[e].b, (row + 1) << 4, kWave), __shfl(S[e].h, (row + 1) << 4, kWave)};
+        if ((row & 1) == 0) S[e] = compose(S[e], p);
+        p = Aff<TC>{__shfl(S[e].a, 32, kWave), __shfl(S[e].b, 32, kWave), __shfl(S[e].h, 32, kWave)};
+        if (row < 2) S[e] = compose(S[e], p);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int e = 0; e < NI; ++e) {
+            sh.a[buf][w][e] = S[e].a;
+            sh.b[buf][w][e] = S[e].b;
+            sh.h[buf][w][e] = S[e].h;
+            if (Op::kNeedsNext) sh.v0[buf][w][e] = op.value(e);
+        }
+    }
+    __syncthreads();
+    TC xs[NI], x_in[NI];
+    TS vn[NI];
+#pragma unroll
+    for (int e = 0; e < NI; ++e) {
+        // carry into this wave from the waves that follow it and from the chunk's carry-in
+        TC x = Xc[e], Cw = Xc[e];
+        TS xv = Xv[e], Cv = Xv[e];
+#pragma unroll
+        for (int k = kWaves - 1; k >= 0; --k) {
+            if (k == w) { Cw = x; Cv = xv; }
+            x = apply(Aff<TC>{sh.a[buf][k][e], sh.b[buf][k][e], sh.h[buf][k][e]}, x);
+            if (Op::kNeedsNext) xv = sh.v0[buf][k][e];
+        }
+        Xc[e] = x;
+        Xv[e] = xv;
+        // exclusive map (everything after this lane inside the wave) = the inclusive one of the next lane
+        Aff<TC> E{dpp_mov<0x130>(S[e].a), dpp_mov<0x130>(S[e].b), dpp_mov<0x130>(S[e].h)};
+        if (lane == kWave - 1) E = Aff<TC>{(TC)1, (TC)0, 0};
+        vn[e] = Op::kNeedsNext ? dpp_mov<0x130>(op.value(e)) : (TS)0;
+        if (Op::kNeedsNext && lane == kWave - 1) vn[e] = Cv;
+        x_in[e] = apply(E, Cw);
+        xs[e] = op.step(e, row_end ? op.init(e) : x_in[e]);  // the reference's exact step from the carry-in
+    }
+    emit(xs, x_in, vn);
+}
+
+template <class Op>
+__device__ __forceinline__ void ls_load(const typename Op::Args &args, i64 step_index, bool valid, typename Op::Raw &raw) {
+    constexpr int NI = Op::V;
+    Op::for_each_input(args, raw, [&](auto *base, auto &arr) {
+        typedef typename std::remove_reference<decltype(arr[0])>::type E;
+        if (!base) return;
+        if (sizeof(E) == 1 && args.mask_bcast) {  // one mask byte per step, shared by its I elements
+            const E m = valid ? base[step_index] : (E)0;
+#pragma unroll
+            for (int e = 0; e < NI; ++e) arr[e] = m;
+        } else {
+            load_n<false>(base, step_index * NI, valid ? NI : 0, arr);
+        }
+    });
+}
+
+template <class Op>
+__global__ __launch_bounds__(kLsThreads) void lockstep_kernel(typename Op::Args args, LsGeom geo, double *partials) {
+    typedef typename Op::TC TC;
+    typedef typename Op::TS TS;
+    typedef typename Op::TO TO;
+    constexpr int NI = Op::V;
+    __shared__ LsShared<Op> sh;
+    __shared__ double red[2 * kLsThreads / kWave];
+    double s = 0.0, ss = 0.0;
+    int buf = 0;
+    auto run = [&](i64 step_index, bool valid, bool row_end, TC (&Xc)[NI], TS (&Xv)[NI]) {
+        typename Op::Raw raw;
+        ls_load<Op>(args, step_index, valid, raw);
+        Op op;
+        op.prepare(args, raw);
+        ls_chunk<Op>(op, sh, buf, valid, row_end, Xc, Xv, [&](const TC(&xs)[NI], const TC(&x_in)[NI], const TS(&vn)[NI]) {
+            TO o0[NI], o1[NI];
+            op.outputs_ls(valid, xs, row_end, x_in, vn, o0, o1, s, ss);
+            store_n<false>(Op::out_ptr(args, 0), step_index * NI, valid ? NI : 0, o0);
+            if (Op::kNumOut > 1) store_n<false>(Op::out_ptr(args, 1), step_index * NI, valid ? NI : 0, o1);
+        });
+        buf ^= 1;
+    };
+    if (geo.rows_per_chunk > 0) {
+        // short rows: R whole outer rows per chunk, every chunk ends at a row end (no carry between chunks)
+        const unsigned T = (unsigned)geo.T;
+        const unsigned lr = threadIdx.x / T, t = threadIdx.x % T;
+        for (i64 c = blockIdx.x; c < geo.nchunks; c += gridDim.x) {
+            const i64 row = c * geo.rows_per_chunk + lr;
+            const bool valid = lr < (unsigned)geo.rows_per_chunk && row < geo.O;
+            TC Xc[NI];
+            TS Xv[NI];
+#pragma unroll
+            for (int e = 0; e < NI; ++e) { Xc[e] = (TC)0; Xv[e] = (TS)0; }
+            run(row * geo.T + t, valid, valid && t == T - 1, Xc, Xv);
+        }
+    } else {
+        for (i64 row = blockIdx.x; row < geo.O; row += gridDim.x) {
+            TC Xc[NI];
+            TS Xv[NI];
+#pragma unroll
+            for (int e = 0; e < NI; ++e) { Xc[e] = (TC)0; Xv[e] = (TS)0; }
+            for (i64 c = geo.nchunks - 1; c >= 0; --c) {
+                const i64 t = c * kLsThreads + threadIdx.x;
+                const bool valid = t < geo.T;
+                run(row * geo.T + t, valid, valid && t == geo.T - 1, Xc, Xv);
+            }
+        }
+    }
+    if (partials) {
+        block_sum2<kLsThreads>(s, ss, red);
+        if (threadIdx.x == 0) {
+            partials[2 * (i64)blockIdx.x] = s;
+            partials[2 * (i64)blockIdx.x + 1] = ss;
+        }
+    }
+}
+
+int ls_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    return n;
+}
+
+template <template <typename, typename, int> class OpT, typename TS, typename TG, int NI, class Args>
+LaunchResult launch_ls(hipStream_t s, const Args &a, double *partials, const char *name) {
+    typedef OpT<TS, TG, NI> Op;
+    static const int cus = ls_cus();
+    LsGeom geo{a.O, a.T, 0, 0};
+    i64 grid;
+    if (a.T <= kLsThreads) {
+        i64 R = kLsThreads / a.T;
+        if (R > a.O) R = a.O;
+        geo.rows_per_chunk = (int)R;
+        geo.nchunks = (a.O + R - 1) / R;
+        grid = geo.nchunks < (i64)cus * 8 ? geo.nchunks : (i64)cus * 8;
+    } else {
+        geo.nchunks = (a.T + kLsThreads - 1) / kLsThreads;
+        grid = a.O < 2048 ? a.O : 2048;
+    }
+    hipLaunchKernelGGL((lockstep_kernel<Op>), dim3((unsigned)grid), dim3(kLsThreads), 0, s, a, geo, partials);
+    return LaunchResult{0, grid, name};
+}
+
+template <template <typename, typename, int> class OpT, class Args>
+LaunchResult dispatch_ls(hipStream_t s, int vdt, int cdt, const Args &a, double *partials, const char *name) {
+    // dtype pairs: (f32, f32), (f64, f64) and (f64 values, f32 coefficients: python-float gamma on fp64 data)
+    if (a.I < 2 || a.I > 8 || (vdt == 0 && cdt == 1) || a.T >= (1LL << 31) - 4096) return LaunchResult{2, 0, nullptr};
+#define TRL_LS_CASE(N)                                                                                  \
+    case N:                                                                                             \
+        if (vdt == 0) return launch_ls<OpT, float, float, N>(s, a, partials, name);                     \
+        if (cdt == 1) return launch_ls<OpT, double, double, N>(s, a, partials, name);                   \
+        return launch_ls<OpT, double, float, N>(s, a, partials, name);
+    switch ((int)a.I) {
+        TRL_LS_CASE(2)
+        TRL_LS_CASE(3)
+        TRL_LS_CASE(4)
+        TRL_LS_CASE(5)
+        TRL_LS_CASE(6)
+        TRL_LS_CASE(7)
+        TRL_LS_CASE(8)
+    }
+#undef TRL_LS_CASE
+    return LaunchResult{2, 0, nullptr};
+}
+
+}  // namespace
+
+LaunchResult launch_gae_lockstep(hipStream_t s, int vdt, int cdt, const GaeArgs &a) {
+    return dispatch_ls<GaeOp>(s, vdt, cdt, a, a.partials, "gae_scan_lockstep");
+}
+LaunchResult launch_td_lambda_lockstep(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a) {
+    return dispatch_ls<TdLambdaOp>(s, vdt, cdt, a, nullptr, "td_lambda_scan_lockstep");
+}
+LaunchResult launch_vtrace_lockstep(hipStream_t s, int vdt, int cdt, const VtraceArgs &a) {
+    return dispatch_ls<VtraceOp>(s, vdt, cdt, a, nullptr, "vtrace_scan_lockstep");
+}

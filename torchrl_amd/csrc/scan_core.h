@@ -88,22 +88,26 @@ __device__ __forceinline__ void vstore(T *__restrict__ p, const T (&in)[V]) {
 }
 template <bool VEC, typename T, int V>
 __device__ __forceinline__ void load_n(const T *__restrict__ p, i64 flat, int nvalid, T (&out)[V]) {
-    if (VEC && nvalid == V) {
-        vload<T, V>(p + flat, out);
-    } else {
-#pragma unroll
-        for (int e = 0; e < V; ++e) out[e] = e < nvalid ? p[flat + e] : (T)0;
+    if constexpr (VEC) {
+        if (nvalid == V) {
+            vload<T, V>(p + flat, out);
+            return;
+        }
     }
+#pragma unroll
+    for (int e = 0; e < V; ++e) out[e] = e < nvalid ? p[flat + e] : (T)0;
 }
 template <bool VEC, typename T, int V>
 __device__ __forceinline__ void store_n(T *__restrict__ p, i64 flat, int nvalid, const T (&in)[V]) {
-    if (VEC && nvalid == V) {
-        vstore<T, V>(p + flat, in);
-    } else {
-#pragma unroll
-        for (int e = 0; e < V; ++e)
-            if (e < nvalid) p[flat + e] = in[e];
+    if constexpr (VEC) {
+        if (nvalid == V) {
+            vstore<T, V>(p + flat, in);
+            return;
+        }
     }
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+        if (e < nvalid) p[flat + e] = in[e];
 }
 
 template <typename T>
@@ -187,6 +191,12 @@ struct GaeOp {
                                             TO (&o1)[V], double &s, double &ss) const {
         finish(nvalid, x, o0, o1, s, ss);
     }
+    // lock-step layout (lockstep_kernels.hip): the lane's V elements are the V feature elements of ONE time step
+    __device__ __forceinline__ TS value(int e) const { return v[e]; }
+    __device__ __forceinline__ void outputs_ls(bool valid, const TC (&x)[V], bool, const TC (&)[V], const TS (&)[V], TO (&o0)[V],
+                                               TO (&o1)[V], double &s, double &ss) const {
+        finish(valid ? V : 0, x, o0, o1, s, ss);
+    }
 };
 
 template <typename TS_, typename TG_, int V_>
@@ -244,6 +254,12 @@ struct TdLambdaOp {
 
     __device__ __forceinline__ void outputs(int, const TC (&x)[V], const bool (&)[V], TC, TS, TO (&o0)[V], TO (&)[V],
                                             double &, double &) const {
+#pragma unroll
+        for (int e = 0; e < V; ++e) o0[e] = (TS)x[e];
+    }
+    __device__ __forceinline__ TS value(int) const { return (TS)0; }
+    __device__ __forceinline__ void outputs_ls(bool, const TC (&x)[V], bool, const TC (&)[V], const TS (&)[V], TO (&o0)[V],
+                                               TO (&)[V], double &, double &) const {
 #pragma unroll
         for (int e = 0; e < V; ++e) o0[e] = (TS)x[e];
     }
@@ -313,6 +329,17 @@ struct VtraceOp {
             const TC nxt = row_end[e] ? (TC)nv[e] : vs_next;  // shift ignores done, functional.py:1343-1345
             adv[e] = (TC)crho[e] * (((TC)r[e] + (TC)td[e] * nxt) - (TC)v[e]);
             if (e < nvalid) vs_next = vs[e];
+        }
+    }
+    // lock-step layout: x_next[e] / v_next[e] are x and state_value of element e of the NEXT time step
+    __device__ __forceinline__ TS value(int e) const { return v[e]; }
+    __device__ __forceinline__ void outputs_ls(bool, const TC (&x)[V], bool row_end, const TC (&x_next)[V], const TS (&v_next)[V],
+                                               TO (&adv)[V], TO (&vs)[V], double &, double &) const {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            vs[e] = x[e] + (TC)v[e];
+            const TC nxt = row_end ? (TC)nv[e] : x_next[e] + (TC)v_next[e];
+            adv[e] = (TC)crho[e] * (((TC)r[e] + (TC)td[e] * nxt) - (TC)v[e]);
         }
     }
 };

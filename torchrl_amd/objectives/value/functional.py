@@ -59,7 +59,7 @@ __all__ = [
 SHAPE_ERR = "All input tensors (value, reward and done states) must share a unique shape."
 _TIME_ERR = "The tensor shape and the time dimension are not compatible: got {} and time_dim={}."
 
-ALGO_AUTO, ALGO_SEQ, ALGO_SCAN, ALGO_FUSED = 0, 1, 2, 3
+ALGO_AUTO, ALGO_SEQ, ALGO_SCAN, ALGO_FUSED, ALGO_LOCKSTEP = 0, 1, 2, 3, 4
 _DT = {torch.float32: 0, torch.float64: 1}
 
 
@@ -390,6 +390,8 @@ def _wants_time_major(c, algo) -> bool:
         return False
     # measured: the re-layout costs ~25 us per million elements (seven transposing copies), SEQ ~32 us at I = 5
     # but ~13 us at I = 31 once there are enough (o, i) rows to hide its per-step latency (~0.46 us * T)
+    if c.I <= 8 and not (c.vdt == torch.float32 and c.cdt == torch.float64):
+        return False  # the lock-step kernels take it as it is
     return c.I <= 8 or c.O * c.I < 16384
 
 
