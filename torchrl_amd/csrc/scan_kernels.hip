@@ -330,10 +330,11 @@ struct LbRecord {             // one 64-byte line per chunk; a field is never re
     unsigned long long pad[3];
 };
 static_assert(sizeof(LbRecord) == 64, "record size");
+constexpr int kLbMaxRows = 512;
 struct LbHeader {
-    unsigned ticket;
     unsigned error;
-    unsigned pad[62];
+    unsigned pad[63];
+    struct { unsigned next; unsigned pad[15]; } row[kLbMaxRows];  // one ticket counter per row, each on its own 64-byte line
 };
 
 template <typename T>
@@ -366,14 +367,14 @@ __global__ __launch_bounds__(kLbTeams * kTeam) void scan_lookback_kernel(typenam
     const int lane_off = (int)(threadIdx.x & (kTeam - 1)) * V;
     const int nchunks = (int)((geo.T + kBlk - 1) / kBlk);
 
-    // One ticket per block: the tickets serialise on one address (~13 ns each, measured), so they -- not HBM --
-    // bound the kernel unless a ticket covers enough bytes.
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&hdr->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // One ticket per block, drawn from its ROW's counter (blocks are dealt to rows round-robin, so the rows'
+    // counters are hit in parallel): atomics on one address serialise (~13 ns each, measured), so they -- not
+    // HBM -- bound the kernel unless a ticket covers enough bytes.
+    const i64 row = blockIdx.x % geo.O;
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&hdr->row[row].next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    const i64 k = s_ticket;
-    const i64 row = k / nchunks;
-    const int c = nchunks - 1 - (int)(k % nchunks);  // later chunks of a row draw earlier tickets
-    if (row >= geo.O) return;
+    const int c = nchunks - 1 - (int)s_ticket;  // later chunks of a row draw earlier tickets
+    if (c < 0) return;
     const i64 t_team = (i64)c * kBlk + (i64)team * kChunk;  // time index of the team's first step
     i64 cnt = geo.T - t_team;
     if (cnt > kChunk) cnt = kChunk;
@@ -566,7 +567,7 @@ Plan make_plan(i64 O, i64 T, i64 I, int V, bool ptr_align_ok, int cus, size_t lb
         // ~13 GB/s per row): scan each row's chunks in parallel with decoupled look-back
         const i64 lb_chunk = chunk * kLbTeams;  // steps per look-back block
         const i64 nch = (T + lb_chunk - 1) / lb_chunk;
-        if (!want_partials && 8 * O < 7 * (i64)cus && T >= 8 * chunk && O * nch <= (1LL << 22) &&
+        if (!want_partials && 8 * O < 7 * (i64)cus && O <= kLbMaxRows && T >= 8 * chunk && O * nch <= (1LL << 22) &&
             lb_bytes >= sizeof(LbHeader) + (size_t)(O * nch) * sizeof(LbRecord)) {
             p.lookback = true;
             p.nchunks = nch;
