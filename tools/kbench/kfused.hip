@@ -1,6 +1,7 @@
 // Ablation harness for the fused GAE+normalise kernel (development tool; not part of the product).
 #include "../../torchrl_amd/csrc/fused_kernels.hip"
 #include "../../torchrl_amd/csrc/norm_kernels.hip"
+xchg::Dev xchg_dev_of(void *) { return xchg::Dev{nullptr, nullptr, 0, 1, 0}; }  // the harness has no communicator
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -40,6 +41,34 @@ int main() {
         run<0, 2>("full (product)", a, geo, ws, G, 500);
         run<4, 2>("last vt deferred", a, geo, ws, G, 500);
         run<1, 2>("no gather", a, geo, ws, G, 500);
+    }
+    for (int stride : {16, 32, 64, 128, 512, 528, 1024, 2064}) {   // slot line spacing: 128 B .. 16 KB (memory-channel spreading)
+        geo.slot_stride = stride;
+        char nm[64]; snprintf(nm, sizeof nm, "slot stride %d B", stride * 8);
+        run<0, 2>(nm, a, geo, ws, G, 1000);
+    }
+    geo.slot_stride = 16;
+    {   // 40 stamped launches back to back: per-launch timeline on the device clock (100 MHz)
+        geo.slot_stride = 16;
+        const int NL = 40;
+        unsigned long long* dbg; CK(hipMalloc(&dbg, (size_t)NL * G * 32));
+        for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((gae_fused_kernel<Op, true, true, 2, 0>), dim3(G), dim3(kFusedThreads), 0, 0, a, geo, ws, (double*)nullptr);
+        for (int l = 0; l < NL; ++l)
+            hipLaunchKernelGGL((gae_fused_kernel<Op, true, true, 2, 7>), dim3(G), dim3(kFusedThreads), 0, 0, a, geo, ws, (double*)(dbg + (size_t)l * G * 4));
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h((size_t)NL * G * 4);
+        CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long prev_end = 0, prev_start = 0;
+        for (int l = 0; l < NL; ++l) {
+            unsigned long long s0 = ~0ull, s1 = 0, p0 = ~0ull, p1 = 0, g1 = 0, e1 = 0;
+            for (int b = 0; b < G; ++b) {
+                const unsigned long long* q = &h[((size_t)l * G + b) * 4];
+                s0 = std::min(s0, q[0]); s1 = std::max(s1, q[0]); p0 = std::min(p0, q[1]); p1 = std::max(p1, q[1]); g1 = std::max(g1, q[2]); e1 = std::max(e1, q[3]);
+            }
+            printf("launch %2d: period %6.2f us | idle before %5.2f | start skew %4.2f  first publish %5.2f  last publish %5.2f  gathered %5.2f  end %5.2f\n", l,
+                   prev_start ? (s0 - prev_start) * 0.01 : 0.0, prev_end ? ((double)s0 - (double)prev_end) * 0.01 : 0.0, (s1 - s0) * 0.01, (p0 - s0) * 0.01, (p1 - s0) * 0.01, (g1 - s0) * 0.01, (e1 - s0) * 0.01);
+            prev_end = e1; prev_start = s0;
+        }
     }
     for (int stride : {16}) {
       geo.slot_stride = stride;

@@ -45,7 +45,8 @@ struct FusedWs {
     unsigned long long slots[1];  // kMaxBlocks granule pairs, kSlotStride 8-byte units apart
 };
 constexpr int kSlotStride = 16;  // one 128-byte line per block: the polls of different blocks do not share a line
-static_assert(256 + (size_t)kMaxBlocks * kSlotStride * 8 <= kFusedWsBytes, "workspace header");
+constexpr int kSlotReplicas = 4;
+static_assert(256 + (size_t)kSlotReplicas * kMaxBlocks * kSlotStride * 8 <= kFusedWsBytes, "workspace header");
 
 struct FusedGeom {
     i64 O, T;
@@ -194,8 +195,12 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
             bss += red[2 * k + 1];
         }
         if constexpr (ABL == 7) stamp1 = wall_clock64();
-        if (lane == 0) {
-            unsigned long long *sl = ws->slots + (size_t)blockIdx.x * geo.slot_stride;
+        // kSlotReplicas copies of every block's granules (lane r writes copy r): the blocks that poll one line drop
+        // from #blocks to #blocks / kSlotReplicas (9.25 -> 9.12 us at C4; 2 / 4 / 8 copies measured, 4 is enough)
+        constexpr int kRep = kSlotReplicas;
+        const size_t rep_off = (size_t)(blockIdx.x % kRep) * gridDim.x * geo.slot_stride;
+        if (lane < kRep) {
+            unsigned long long *sl = ws->slots + ((size_t)lane * gridDim.x + blockIdx.x) * geo.slot_stride;
             __hip_atomic_store(sl, tag_bits(bs, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sl + 1, tag_bits(bss, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
 #pragma unroll
             for (int j = 0; j < kPer; ++j) {
                 if (!got[j]) {
-                    const unsigned long long *sl = ws->slots + (size_t)(lane + kWave * j) * geo.slot_stride;
+                    const unsigned long long *sl = ws->slots + rep_off + (size_t)(lane + kWave * j) * geo.slot_stride;
                     vs[j] = __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     vq[j] = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -228,7 +233,8 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
             }
             if (__all(ok)) break;
             if (wall_clock64() - t_start > 100000000ull) break;  // 1 s at 100 MHz: give up loudly
-            __builtin_amdgcn_s_sleep(1);  // sleep 0 / 4 / 10 and pipelined polls measured: no gain (polls flood the fabric)
+            __builtin_amdgcn_s_sleep(1);  // sleep 0 / 4 / 10: no gain; two or three poll rounds in flight (also of the missing
+                                          // granules only): 16 - 23 us -- extra polls slow the publishes down
         }
         const bool all_ok = __all(ok);
         if constexpr (ABL == 7) stamp2 = wall_clock64();
