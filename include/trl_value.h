@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TRL_ABI_VERSION 3
+#define TRL_ABI_VERSION 4
 
 enum { TRL_F32 = 0, TRL_F64 = 1 };
 
@@ -98,6 +98,13 @@ int trl_workspace_error(const void *workspace);
  *   the I feature elements of a step (what a stride-0 `expand` of a per-env mask over the agent
  *   dimension means, sota-implementations/multiagent/utils/utils.py:34-43) and are read in place.
  *   Ignored when I == 1.  Same meaning in every entry point below.
+ * next_state_value == NULL (ABI 4): SHIFTED value layout.  `state_value` then points to a contiguous
+ *   (O, T + 1, I) buffer -- the value network evaluated once on the T steps plus the last next-observation
+ *   (what `shifted=True` produces, torchrl/objectives/value/advantages.py:440-490) -- and v_t / v'_t are its
+ *   elements (o, t, i) / (o, t + 1, i), read in place: the value bytes are fetched once (fp32 GAE:
+ *   22 -> 18 B per transition).  Outputs keep the (O, T, I) layout.  Needs I == 1 (any kernel family but
+ *   LOCKSTEP) or TRL_ALGO_SEQ (any I); TRL_ERR_UNSUPPORTED otherwise.  Same meaning in
+ *   trl_gae_normalize_fwd, trl_gae_normalize_xchg_fwd and trl_vtrace_fwd.
  * stats (optional, device double[3]): receives {N, sum(A), sum(A^2)} accumulated in fp64 in a
  *   fixed order (deterministic); needs `workspace` of trl_workspace_bytes().  It feeds
  *   trl_normalize() (after an all-reduce when the batch is sharded over GPUs).

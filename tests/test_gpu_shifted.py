@@ -1,0 +1,191 @@
+"""GPU (-m gpu): the shifted value layout (reference advantages.py:440-490, `shifted=True`):
+state_value / next_state_value are the [0, T) / [1, T + 1) windows of one [*B, T + 1, 1] buffer, and the kernels
+read that buffer in place (trl_value.h: next_state_value == NULL).  Expected: the same bits as the dense call on
+contiguous copies of the two windows (same arithmetic, another addressing), and the oracle within tolerance."""
+import ctypes
+
+import pytest
+import torch
+
+from oracle import value_oracle as O
+from torchrl_amd import _extension
+from torchrl_amd.objectives.value import functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def tol(dtype):
+    return dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-12, atol=1e-12)
+
+
+def _inputs(batch, T, feat, dtype, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    shape = (*batch, T, *feat)
+    buf = torch.randn((*batch, T + 1, *feat), generator=g, dtype=torch.float32).to(dtype)
+    r = torch.randn(shape, generator=g, dtype=torch.float32).to(dtype)
+    term = torch.rand(shape, generator=g) < 0.03
+    done = term | (torch.rand(shape, generator=g) < 0.03)
+    gam = (0.9 + 0.1 * torch.rand(shape, generator=g)).to(dtype)
+    lp = torch.rand(shape, generator=g).clamp_min(1e-6).log().to(dtype)
+    lm = torch.rand(shape, generator=g).clamp_min(1e-6).log().to(dtype)
+    return buf, r, done, term, gam, lp, lm
+
+
+# short rows (one chunk holds many), ragged rows (T % V != 0, T < V), rows of several chunks, look-back rows
+SHAPES = [((64,), 32), ((300,), 32), ((37,), 100), ((5,), 7), ((33,), 3), ((9,), 1), ((1,), 2048), ((3,), 2500),
+          ((7, 3), 33), ((130,), 128), ((7,), 1025), ((2,), 40000)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("batch,T", SHAPES, ids=["x".join(map(str, b)) + f"x{t}" for b, t in SHAPES])
+@pytest.mark.parametrize("tensor_gamma", [False, True], ids=["g_scalar", "g_tensor"])
+def test_shifted_equals_dense(batch, T, dtype, tensor_gamma):
+    buf, r, done, term, gam, lp, lm = _inputs(batch, T, (1,), dtype, seed=T)
+    gamma = gam if tensor_gamma else 0.99
+    v, nv = buf.narrow(-2, 0, T), buf.narrow(-2, 1, T)
+    oadv, ovt = O.gae(gamma, 0.95, v, nv, r, done, term)
+    ova, ovs = O.vtrace(gamma, lp, lm, v, nv, r, done, term)
+    bufd, r_, done_, term_, lp_, lm_ = (x.to(DEV) for x in (buf, r, done, term, lp, lm))
+    gamma_ = gamma.to(DEV) if tensor_gamma else gamma
+    vs_, nvs_ = bufd.narrow(-2, 0, T), bufd.narrow(-2, 1, T)
+    shifted = F._prepare_gae(gamma_, 0.95, vs_, nvs_, r_, done_, term_, -2)
+    dense = F._prepare_gae(gamma_, 0.95, vs_.clone(), nvs_.clone(), r_, done_, term_, -2)
+    assert shifted.next_value is None and dense.next_value is not None
+    for algo in (F.ALGO_AUTO, F.ALGO_SEQ, F.ALGO_SCAN):
+        a1, t1, s1 = F._launch_gae(shifted, want_stats=True, algo=algo)
+        k1 = F.last_kernel()
+        a2, t2, s2 = F._launch_gae(dense, want_stats=True, algo=algo)
+        assert F.last_kernel() == k1
+        assert torch.equal(a1, a2) and torch.equal(t1, t2) and torch.equal(s1, s2), (algo, k1)
+        torch.testing.assert_close(a1.cpu(), oadv, **tol(dtype))
+        torch.testing.assert_close(t1.cpu(), ovt, **tol(dtype))
+        assert torch.equal(a1.cpu()[done], oadv[done])
+    # GAE + normalisation (single launch where eligible)
+    n1 = F._launch_gae_normalize(shifted, 1e-4)
+    k1 = F.last_kernel()
+    n2 = F._launch_gae_normalize(dense, 1e-4)
+    assert F.last_kernel() == k1
+    assert torch.equal(n1[0], n2[0], ) or (torch.isnan(n1[0]).all() and torch.isnan(n2[0]).all())
+    assert torch.equal(n1[1], n2[1])
+    # V-trace
+    vsh = F._prepare_vtrace(gamma_, lp_, lm_, vs_, nvs_, r_, done_, term_, 1.0, 1.0, -2)
+    vde = F._prepare_vtrace(gamma_, lp_, lm_, vs_.clone(), nvs_.clone(), r_, done_, term_, 1.0, 1.0, -2)
+    assert vsh.next_value is None
+    for algo in (F.ALGO_AUTO, F.ALGO_SEQ, F.ALGO_SCAN):
+        a1, x1 = F._launch_vtrace(vsh, algo=algo)
+        a2, x2 = F._launch_vtrace(vde, algo=algo)
+        assert torch.equal(a1, a2) and torch.equal(x1, x2), algo
+        torch.testing.assert_close(a1.cpu(), ova, **tol(ova.dtype))
+        torch.testing.assert_close(x1.cpu(), ovs, **tol(ovs.dtype))
+
+
+def test_shifted_headline_shape_single_launch():
+    """[65536 x 32] fp32 GAE + normalise from the shifted buffer: the fused kernel, same bits as the dense call."""
+    buf, r, done, term, *_ = _inputs((65536,), 32, (1,), torch.float32, seed=4)
+    bufd, r_, done_, term_ = (x.to(DEV) for x in (buf, r, done, term))
+    v_, nv_ = bufd[:, :-1], bufd[:, 1:]
+    a1, t1 = F.gae_normalized(0.99, 0.95, v_, nv_, r_, done_, term_)
+    assert F.last_kernel().startswith("gae_fused")
+    a2, t2 = F.gae_normalized(0.99, 0.95, v_.clone(), nv_.clone(), r_, done_, term_)
+    assert torch.equal(a1, a2) and torch.equal(t1, t2)
+    oadv, ovt = O.gae(0.99, 0.95, buf[:, :-1], buf[:, 1:], r, done, term)
+    ref = (oadv - oadv.mean()) / oadv.std().clamp_min(1e-4)
+    torch.testing.assert_close(a1.cpu(), ref, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(t1.cpu(), ovt, rtol=1e-5, atol=1e-5)
+    assert not F.workspace_error()
+
+
+@pytest.mark.parametrize("layout", ["time_last", "two_feature_dims", "offset_view", "batch_of_one"])
+def test_shifted_detection_layouts(layout):
+    T = 50
+    g = torch.Generator().manual_seed(1)
+    if layout == "time_last":  # [B, T + 1], time_dim = -1
+        buf, td = torch.randn(12, T + 1, generator=g), -1
+    elif layout == "two_feature_dims":  # [B, T + 1, 1, 1], time_dim = -3
+        buf, td = torch.randn(12, T + 1, 1, 1, generator=g), -3
+    elif layout == "offset_view":  # the buffer itself is a slice of a larger allocation
+        buf, td = torch.randn(20, T + 1, 1, generator=g)[5:17], -2
+    else:
+        buf, td = torch.randn(1, T + 1, 1, generator=g), -2
+    dim = buf.ndim + td
+    v, nv = buf.narrow(dim, 0, T), buf.narrow(dim, 1, T)
+    r = torch.randn(v.shape, generator=g)
+    done = torch.rand(v.shape, generator=g) < 0.05
+    bufd = torch.empty(buf.shape, device=DEV) if layout != "offset_view" else torch.empty(20, T + 1, 1, device=DEV)[5:17]
+    bufd.copy_(buf)
+    v_, nv_ = bufd.narrow(dim, 0, T), bufd.narrow(dim, 1, T)
+    call = F._prepare_gae(0.99, 0.95, v_, nv_, r.to(DEV), done.to(DEV), None, td)
+    assert call.next_value is None
+    adv, vt = F.generalized_advantage_estimate(0.99, 0.95, v_, nv_, r.to(DEV), done.to(DEV), time_dim=td)
+    oadv, ovt = O.gae(0.99, 0.95, v, nv, r, done, done, time_dim=td)
+    torch.testing.assert_close(adv.cpu(), oadv, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(vt.cpu(), ovt, rtol=1e-5, atol=1e-5)
+
+
+def test_not_shifted_when_the_windows_do_not_line_up():
+    buf = torch.randn(8, 21, 1, device=DEV)
+    r = torch.randn(8, 20, 1, device=DEV)
+    d = torch.zeros(8, 20, 1, dtype=torch.bool, device=DEV)
+    prep = lambda v, nv, **kw: F._prepare_gae(0.99, 0.95, v, nv, r, d, None, -2)
+    assert prep(buf[:, :-1], buf[:, 1:]).next_value is None
+    assert prep(buf[:, 1:], buf[:, :-1]).next_value is not None            # reversed roles
+    assert prep(buf[:, :-1], buf[:, 1:].clone()).next_value is not None    # another storage
+    assert prep(buf[:, :-1].double(), buf[:, 1:].double()).next_value is not None
+    wide = torch.randn(8, 22, 1, device=DEV)
+    assert prep(wide[:, :20], wide[:, 1:21]).next_value is not None        # rows are T + 2 apart
+    v = buf[:, :-1].requires_grad_(True)
+    assert prep(v, buf[:, 1:]).next_value is not None                      # autograd takes the dense path
+    multi = torch.randn(8, 21, 3, device=DEV)                              # I = 3: dense copies
+    r3, d3 = torch.randn(8, 20, 3, device=DEV), torch.zeros(8, 20, 3, dtype=torch.bool, device=DEV)
+    assert F._prepare_gae(0.99, 0.95, multi[:, :-1], multi[:, 1:], r3, d3, None, -2).next_value is not None
+
+
+def test_c_abi_shifted_with_feature_elements():
+    """next_state_value == NULL with I > 1: TRL_ALGO_SEQ reads the (O, T + 1, I) buffer, the other families refuse."""
+    lib = _extension.get_lib()
+    O_, T, I = 6, 40, 3
+    g = torch.Generator().manual_seed(2)
+    buf = torch.randn(O_, T + 1, I, generator=g)
+    r = torch.randn(O_, T, I, generator=g)
+    done = torch.rand(O_, T, I, generator=g) < 0.05
+    oadv, ovt = O.gae(0.99, 0.95, buf[:, :-1], buf[:, 1:], r, done, done, time_dim=-2)
+    bufd, r_, d_ = buf.to(DEV), r.to(DEV), done.to(DEV).view(torch.uint8)
+    adv, vt = torch.empty_like(r_), torch.empty_like(r_)
+    f32 = torch.tensor(0.99 * 0.95, dtype=torch.float32)
+
+    def call(algo):
+        return lib.trl_gae_fwd(torch.cuda.current_stream().cuda_stream, 0, 0, r_.data_ptr(), bufd.data_ptr(), None, d_.data_ptr(),
+                               d_.data_ptr(), 0, None, None, float(torch.tensor(0.99, dtype=torch.float32)), 0.0,
+                               float(torch.tensor(0.95, dtype=torch.float32) * torch.tensor(0.99, dtype=torch.float32)),
+                               O_, T, I, adv.data_ptr(), vt.data_ptr(), None, None, 0, algo)
+
+    assert call(F.ALGO_SEQ) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(adv.cpu(), oadv) and torch.equal(vt.cpu(), ovt)
+    for algo in (F.ALGO_AUTO, F.ALGO_SCAN, F.ALGO_LOCKSTEP):
+        assert call(algo) == 2  # TRL_ERR_UNSUPPORTED
+        assert b"shifted" in lib.trl_last_error()
+
+
+@pytest.mark.parametrize("average_gae", [False, True])
+def test_gae_module_shifted_reads_the_single_call_buffer_in_place(monkeypatch, average_gae):
+    """GAE(shifted=True): the value network runs once on T + 1 steps and the kernels read its output in place."""
+    from torch import nn
+
+    from torchrl_amd.objectives.value import GAE, KeyedModule
+
+    torch.manual_seed(0)
+    net = KeyedModule(nn.Linear(3, 1).to(DEV), ["obs"], ["state_value"])
+    seq = torch.randn(64, 33, 3, device=DEV)
+    reward = torch.randn(64, 32, 1, device=DEV)
+    done = torch.rand(64, 32, 1, device=DEV) < 0.05
+    seen = []
+    real = F._shifted_pair
+    monkeypatch.setattr(F, "_shifted_pair", lambda *a: seen.append(real(*a)) or seen[-1])
+    kw = dict(obs=seq[:, :-1], next_obs=seq[:, 1:], next_reward=reward, next_done=done, next_terminated=done)
+    a1, t1 = GAE(gamma=0.98, lmbda=0.94, value_network=net, average_gae=average_gae)(**kw)
+    a2, t2 = GAE(gamma=0.98, lmbda=0.94, value_network=net, average_gae=average_gae, shifted=True)(**kw)
+    assert seen == [False, True]
+    torch.testing.assert_close(a1, a2, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(t1, t2, rtol=1e-5, atol=1e-5)

@@ -180,3 +180,30 @@ def test_library_binds_to_torchs_hip_runtime_whatever_the_import_order():
     out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split()[0] == "1", out.stdout
+
+
+def test_shifted_pair_detection():
+    """state_value / next_state_value as the two T-step windows of one [*B, T + 1, 1] buffer (advantages.py:440-490,
+    `shifted=True`) are recognised from strides and storage offsets alone; anything else takes the dense path."""
+    sp = lambda v, nv, td=-2, grads=False: F._shifted_pair(v, nv, tuple(v.shape), td, v.dtype, grads)
+    buf = torch.randn(6, 11, 1)
+    assert sp(buf[:, :-1], buf[:, 1:])
+    assert not sp(buf[:, 1:], buf[:, :-1])
+    assert not sp(buf[:, :-1], buf[:, 1:].clone())
+    assert not sp(buf[:, :-1], buf[:, 1:], grads=True)
+    assert not sp(buf[:, :9], buf[:, 1:10])                       # rows T + 2 apart
+    assert not sp(buf[:, :-1], buf[:, 1:].double())
+    flat = torch.randn(6, 11)
+    assert sp(flat[:, :-1], flat[:, 1:], td=-1)                   # no feature dim, time last
+    four = torch.randn(2, 3, 11, 1, 1)
+    assert sp(four[:, :, :-1], four[:, :, 1:], td=-3) and sp(four[:, :, :-1], four[:, :, 1:], td=2)
+    part = torch.randn(9, 11, 1)
+    assert sp(part[2:8, :-1], part[2:8, 1:])                      # a batch slice of a larger buffer
+    assert not sp(part[::2, :-1], part[::2, 1:])                  # rows not T + 1 apart
+    multi = torch.randn(6, 11, 3)
+    assert not sp(multi[:, :-1], multi[:, 1:])                    # I = 3: the kernels' shifted path needs I == 1
+    one = torch.randn(1, 11, 1)
+    assert sp(one[:, :-1], one[:, 1:])                            # a single row: both windows are contiguous views
+    tm = torch.randn(11, 6, 1)                                    # time-major storage seen batch-first
+    assert not sp(tm[:-1].transpose(0, 1), tm[1:].transpose(0, 1))
+    assert not sp(torch.empty(0, 11, 1)[:, :-1], torch.empty(0, 11, 1)[:, 1:])

@@ -18,7 +18,7 @@ import warnings
 
 _LIB_NAME = "libtrl_value.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXTENSION_WARNING = (
     f"Failed to load the torchrl_amd HIP library ({_LIB_PATH}). The value estimators "

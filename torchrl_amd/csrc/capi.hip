@@ -65,6 +65,16 @@ void *lb_region(void *workspace, size_t workspace_bytes, i64 O, i64 T, i64 I, si
 
 }  // namespace
 
+// Shifted value layout: next_state_value == NULL, state_value is the (O, T + 1, I) buffer (trl_value.h).
+// The wavefront-scan and fused kernels read it for I == 1; the SEQ kernels for any I.
+static int check_shifted(const char *fn, const void *next_state_value, int64_t I, int algo) {
+    if (next_state_value) return TRL_OK;
+    if (I != 1 && algo != TRL_ALGO_SEQ)
+        return fail(TRL_ERR_UNSUPPORTED, "%s: the shifted value layout (next_state_value == NULL) needs I == 1 or TRL_ALGO_SEQ (I = %lld)",
+                    fn, (long long)I);
+    return TRL_OK;
+}
+
 // I > 1 with whole outer rows inside one chunk: both the LDS-transposing SCAN kernel and the lock-step kernels
 // apply.  Measured (fp32 / fp64, T = 32..100, I = 2..8): the transposing kernel wins when its chunk is full
 // (R*T*I >= 95 % of 256*V elements: [8192x100x5] 23.0 vs 23.3 us, [8192x32x8] 11.4 vs 14.8), the lock-step
@@ -113,8 +123,9 @@ int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward,
                 double *stats, void *workspace, size_t workspace_bytes, int algo) {
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: bad dtype");
     if (int rc = check_dims("trl_gae_fwd", O, T, I)) return rc;
-    if (!reward || !state_value || !next_state_value || !done || !terminated || !advantage || !value_target)
+    if (!reward || !state_value || !done || !terminated || !advantage || !value_target)
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: null tensor pointer");
+    if (int rc = check_shifted("trl_gae_fwd", next_state_value, I, algo)) return rc;
     if (lg_t && !gamma_t) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: lg_t given without gamma_t");
     if (stats) {
         if (!workspace || workspace_bytes < trl_workspace_bytes(O, T, I))
@@ -194,8 +205,9 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_
                    void *advantage, void *vs, void *workspace, size_t workspace_bytes, int algo) {
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_fwd: bad dtype");
     if (int rc = check_dims("trl_vtrace_fwd", O, T, I)) return rc;
-    if (!log_pi || !log_mu || !state_value || !next_state_value || !reward || !done || !terminated || !advantage || !vs)
+    if (!log_pi || !log_mu || !state_value || !reward || !done || !terminated || !advantage || !vs)
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_fwd: null tensor pointer");
+    if (int rc = check_shifted("trl_vtrace_fwd", next_state_value, I, algo)) return rc;
     VtraceArgs a{log_pi, log_mu, state_value, next_state_value, reward, done, terminated, gamma_t,
                  gamma, rho_thresh, c_thresh, O, T, I, advantage, vs, (mask_bcast && I > 1) ? 1 : 0};
     hipStream_t s = (hipStream_t)stream;
@@ -227,8 +239,9 @@ static int gae_normalize_impl(void *stream, int val_dtype, int coef_dtype, const
                               double *stats, void *workspace, size_t workspace_bytes, void *comm, int algo) {
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_normalize_fwd: bad dtype");
     if (int rc = check_dims("trl_gae_normalize_fwd", O, T, I)) return rc;
-    if (!reward || !state_value || !next_state_value || !done || !terminated || !advantage || !value_target)
+    if (!reward || !state_value || !done || !terminated || !advantage || !value_target)
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_normalize_fwd: null tensor pointer");
+    if (int rc = check_shifted("trl_gae_normalize_fwd", next_state_value, I, algo)) return rc;
     if (lg_t && !gamma_t) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_normalize_fwd: lg_t given without gamma_t");
     if (!workspace || workspace_bytes < trl_workspace_bytes(O, T, I) || ((uintptr_t)workspace & 255) != 0)
         return fail(TRL_ERR_WORKSPACE, "trl_gae_normalize_fwd: workspace is %zu bytes, need %zu (256-byte aligned, zero-filled once)",

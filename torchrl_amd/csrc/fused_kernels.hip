@@ -326,7 +326,7 @@ LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *w
     const i64 per_iter = (i64)G * kTeams;
     const i64 k_needed = (nchunks + per_iter - 1) / per_iter;
     if (k_needed > 4) return LaunchResult{2, 0, nullptr};  // advantages would not fit in registers
-    const bool al = aligned16(a.reward) && aligned16(a.value) && aligned16(a.next_value) && aligned16(a.done) &&
+    const bool al = aligned16(a.reward) && (!a.next_value || aligned16(a.value)) && aligned16(a.next_value) && aligned16(a.done) &&
                     aligned16(a.terminated) && aligned16(a.gamma_t) && aligned16(a.lg_t) && aligned16(a.advantage) &&
                     aligned16(a.value_target);
     const bool vec = al && (nchunks == 1 || (R * a.T) % V == 0);
@@ -347,6 +347,13 @@ LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *w
 
 LaunchResult launch_gae_fused(hipStream_t s, int vdt, int cdt, const GaeArgs &a, double eps, void *ws, double *stats_out, void *comm) {
     const xchg::Dev xd = xchg_dev_of(comm);
+    if (!a.next_value) {  // shifted value layout: its own instantiations (scan_core.h: Shifted<>)
+        if (vdt == 0 && cdt == 0) return launch_fused_t<GaeShiftedOp<float, float, 4>>(s, a, eps, ws, stats_out, xd);
+        if (vdt == 1 && cdt == 1) return launch_fused_t<GaeShiftedOp<double, double, 2>>(s, a, eps, ws, stats_out, xd);
+        if (vdt == 1 && cdt == 0) return launch_fused_t<GaeShiftedOp<double, float, 2>>(s, a, eps, ws, stats_out, xd);
+        if (vdt == 0 && cdt == 1) return launch_fused_t<GaeShiftedOp<float, double, 4>>(s, a, eps, ws, stats_out, xd);
+        return LaunchResult{1, 0, nullptr};
+    }
     if (vdt == 0 && cdt == 0) return launch_fused_t<GaeOp<float, float, 4>>(s, a, eps, ws, stats_out, xd);
     if (vdt == 1 && cdt == 1) return launch_fused_t<GaeOp<double, double, 2>>(s, a, eps, ws, stats_out, xd);
     if (vdt == 1 && cdt == 0) return launch_fused_t<GaeOp<double, float, 2>>(s, a, eps, ws, stats_out, xd);

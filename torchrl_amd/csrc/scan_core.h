@@ -115,6 +115,50 @@ __device__ __forceinline__ T clamp_max_nan(T x, T hi) { return (x != x) ? x : (x
 __device__ __forceinline__ float exp_t(float x) { return expf(x); }
 __device__ __forceinline__ double exp_t(double x) { return exp(x); }
 
+// ---- shifted value layout (I == 1) -----------------------------------------------------------
+// The value network was evaluated once on T + 1 steps per row (reference: advantages.py:440-490,
+// `shifted=True`): state_value and next_state_value are the two T-step windows [0, T) and [1, T + 1)
+// of ONE (O, T + 1) buffer.  The kernels then read that buffer in place: element `flat` of the (O, T)
+// index space sits at flat + flat / T, its successor right behind it, so a lane that owns V steps of
+// one row issues V + 1 scalar loads instead of two V-wide ones and the value bytes come from HBM once
+// (GAE fp32: 22 -> 18 B per transition).  Rows are T + 1 elements apart, hence never 16-byte
+// aligned as a whole: these loads stay scalar.
+// flat / T without the 64-bit integer division (whose expansion kept the callers' register arrays in scratch):
+// exact for flat < 2^52 after one correction step.
+__device__ __forceinline__ i64 row_of(i64 flat, i64 T) {
+    if ((((unsigned long long)flat | (unsigned long long)T) >> 32) == 0) return (i64)((unsigned)flat / (unsigned)T);
+    i64 row = (i64)((double)flat / (double)T);
+    const i64 rem = flat - row * T;
+    row += rem >= T ? 1 : (rem < 0 ? -1 : 0);
+    return row;
+}
+template <typename TS, int V>
+__device__ __forceinline__ void load_shifted_pair(const TS *__restrict__ buf, i64 flat, i64 T, int nvalid, TS (&v)[V],
+                                                  TS (&nv)[V]) {
+    const i64 row = row_of(flat, T);
+    unsigned t = (unsigned)(flat - row * T);
+    const TS *__restrict__ p = buf + flat + row;
+    if (nvalid == V && (i64)t + V <= T) {  // the lane's V steps share a row: V + 1 consecutive elements
+        // (fetching the two 16-byte granules that hold the window with vector loads and picking it with selects
+        // was measured slower than these V + 1 scalar loads: 9.69 vs 9.40 us for the fused kernel at [65536 x 32])
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = p[e];
+#pragma unroll
+        for (int e = 0; e + 1 < V; ++e) nv[e] = v[e + 1];
+        nv[V - 1] = p[V];
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {  // ragged: a row ends inside the lane's steps (one buffer element is skipped there)
+        const bool ok = e < nvalid;
+        v[e] = ok ? p[0] : (TS)0;
+        nv[e] = ok ? p[1] : (TS)0;
+        ++t;
+        p += (t == (unsigned)T) ? 2 : 1;
+        t = (t == (unsigned)T) ? 0u : t;
+    }
+}
+
 // ---- per-estimator element logic -------------------------------------------------------------
 // Each Op holds one lane's V consecutive time steps.  Interface used by the scan driver:
 //   Raw, for_each_input(args, raw, f)  the input tensors and the lane's V raw elements of each
@@ -136,11 +180,23 @@ struct GaeOp {
     typedef GaeArgs Args;
     static constexpr int V = V_;
     static constexpr bool kNeedsNext = false;
+    static constexpr bool kShifted = false;  // see Shifted<> below
     struct Raw {
         TS r[V], v[V], nv[V];
         u8 d[V], tm[V];
         TG g[V], lg[V];
     };
+    template <class F>
+    static __device__ __forceinline__ void for_each_unshifted_input(const Args &a, Raw &w, F &&f) {
+        f((const TS *)a.reward, w.r);
+        f(a.done, w.d);
+        f(a.terminated, w.tm);
+        f((const TG *)a.gamma_t, w.g);
+        f((const TG *)a.lg_t, w.lg);
+    }
+    static __device__ __forceinline__ void load_shifted(const Args &a, i64 flat, int nvalid, Raw &w) {
+        load_shifted_pair<TS, V>((const TS *)a.value, flat, a.T, nvalid, w.v, w.nv);
+    }
     TS v[V];
     TC delta[V], disc[V];
 
@@ -207,6 +263,7 @@ struct TdLambdaOp {
     typedef TdLambdaArgs Args;
     static constexpr int V = V_;
     static constexpr bool kNeedsNext = false;
+    static constexpr bool kShifted = false;
     struct Raw {
         TS r[V], nv[V];
         u8 d[V], tm[V];
@@ -273,11 +330,24 @@ struct VtraceOp {
     typedef VtraceArgs Args;
     static constexpr int V = V_;
     static constexpr bool kNeedsNext = true;
+    static constexpr bool kShifted = false;
     struct Raw {
         TS lp[V], lmu[V], v[V], nv[V], r[V];
         u8 d[V], tm[V];
         TG g[V];
     };
+    template <class F>
+    static __device__ __forceinline__ void for_each_unshifted_input(const Args &a, Raw &w, F &&f) {
+        f((const TS *)a.log_pi, w.lp);
+        f((const TS *)a.log_mu, w.lmu);
+        f((const TS *)a.reward, w.r);
+        f(a.done, w.d);
+        f(a.terminated, w.tm);
+        f((const TG *)a.gamma_t, w.g);
+    }
+    static __device__ __forceinline__ void load_shifted(const Args &a, i64 flat, int nvalid, Raw &w) {
+        load_shifted_pair<TS, V>((const TS *)a.value, flat, a.T, nvalid, w.v, w.nv);
+    }
     TS v[V], nv[V], r[V], crho[V];
     TG td[V];
     TC coef[V], delta[V];
@@ -344,9 +414,28 @@ struct VtraceOp {
     }
 };
 
+// The same estimator reading the shifted value layout (load_shifted_pair): a separate kernel instantiation, so
+// that the dense kernels keep their register budget (a run-time switch inside one kernel cost the fused
+// GAE + normalise kernel its occupancy: 9.3 -> 20.7 us at [65536 x 32]).
+template <class Base>
+struct Shifted : Base {
+    static constexpr bool kShifted = true;
+};
+template <typename TS, typename TG, int V>
+using GaeShiftedOp = Shifted<GaeOp<TS, TG, V>>;
+template <typename TS, typename TG, int V>
+using VtraceShiftedOp = Shifted<VtraceOp<TS, TG, V>>;
+
 // ---- generic load / store over an Op's tensor lists ------------------------------------------------
 template <class Op, bool VEC>
 __device__ __forceinline__ void load_inputs(const typename Op::Args &a, i64 flat, int nvalid, typename Op::Raw &w) {
+    if constexpr (Op::kShifted) {
+        Op::for_each_unshifted_input(a, w, [&](auto *base, auto &dst) {
+            if (base) load_n<VEC>(base, flat, nvalid, dst);
+        });
+        Op::load_shifted(a, flat, nvalid, w);
+        return;
+    }
     Op::for_each_input(a, w, [&](auto *base, auto &dst) {
         if (base) load_n<VEC>(base, flat, nvalid, dst);
     });

@@ -582,11 +582,16 @@ LaunchResult launch_scan(hipStream_t s, const typename Op::Args &a, const Plan &
                          const char *name, void *lb_ws = nullptr) {
     ScanGeom geo{O, T, p.rows_per_chunk, scan_lanes_for(T, Op::V, p.wave_indep), p.nchunks};
     const dim3 grid((unsigned)p.nblocks);
+    if constexpr (Op::kShifted) {
+        if (p.interleaved) return LaunchResult{2, 0, nullptr};  // the shifted layout is read by the I == 1 kernels only
+    }
     if (p.interleaved) {
+      if constexpr (!Op::kShifted) {
 #define TRL_LAUNCH(VEC, WI) hipLaunchKernelGGL((scan_interleaved_kernel<Op, VEC, WI>), grid, dim3(kTeam), 0, s, a, geo, (int)I, partials)
         if (p.wave_indep) { if (p.vec) TRL_LAUNCH(true, true); else TRL_LAUNCH(false, true); }
         else              { if (p.vec) TRL_LAUNCH(true, false); else TRL_LAUNCH(false, false); }
 #undef TRL_LAUNCH
+      }
     } else if (p.lookback) {
         LbHeader *hdr = (LbHeader *)lb_ws;
         LbRecord *rec = (LbRecord *)((char *)lb_ws + sizeof(LbHeader));
@@ -634,16 +639,18 @@ i64 scan_max_partials(i64 O, i64 T, i64 I) {
 }
 
 LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a, void *lb_ws, size_t lb_bytes) {
-    const bool al = aligned16(a.reward) && aligned16(a.value) && aligned16(a.next_value) && aligned16(a.done) &&
+    // shifted layout (next_value == nullptr): the value buffer is read with scalar loads whatever its alignment
+    const bool al = aligned16(a.reward) && (!a.next_value || aligned16(a.value)) && aligned16(a.next_value) && aligned16(a.done) &&
                     aligned16(a.terminated) && aligned16(a.gamma_t) && aligned16(a.lg_t) && aligned16(a.advantage) &&
                     aligned16(a.value_target);
-    return dispatch_scan<GaeOp, GaeArgs>(vdt, cdt, [&](auto op) {
+    auto go = [&](auto op) {
         typedef decltype(op) Op;
         Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus(), lb_ws ? lb_bytes : 0, a.partials != nullptr);
         if (!p.ok) return LaunchResult{2, 0, nullptr};
         return launch_scan<Op>(s, a, p, a.O, a.T, a.I, a.partials,
                                p.interleaved ? "gae_scan_interleaved" : p.lookback ? "gae_scan_lookback" : p.long_rows ? "gae_scan_long" : "gae_scan_short", lb_ws);
-    });
+    };
+    return a.next_value ? dispatch_scan<GaeOp, GaeArgs>(vdt, cdt, go) : dispatch_scan<GaeShiftedOp, GaeArgs>(vdt, cdt, go);
 }
 
 LaunchResult launch_td_lambda_scan(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, void *lb_ws, size_t lb_bytes) {
@@ -659,14 +666,15 @@ LaunchResult launch_td_lambda_scan(hipStream_t s, int vdt, int cdt, const TdLamb
 }
 
 LaunchResult launch_vtrace_scan(hipStream_t s, int vdt, int cdt, const VtraceArgs &a, void *lb_ws, size_t lb_bytes) {
-    const bool al = aligned16(a.log_pi) && aligned16(a.log_mu) && aligned16(a.value) && aligned16(a.next_value) &&
+    const bool al = aligned16(a.log_pi) && aligned16(a.log_mu) && (!a.next_value || aligned16(a.value)) && aligned16(a.next_value) &&
                     aligned16(a.reward) && aligned16(a.done) && aligned16(a.terminated) && aligned16(a.gamma_t) &&
                     aligned16(a.advantage) && aligned16(a.vs);
-    return dispatch_scan<VtraceOp, VtraceArgs>(vdt, cdt, [&](auto op) {
+    auto go = [&](auto op) {
         typedef decltype(op) Op;
         Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus(), lb_ws ? lb_bytes : 0, false);
         if (!p.ok) return LaunchResult{2, 0, nullptr};
         return launch_scan<Op>(s, a, p, a.O, a.T, a.I, nullptr,
                                p.interleaved ? "vtrace_scan_interleaved" : p.lookback ? "vtrace_scan_lookback" : p.long_rows ? "vtrace_scan_long" : "vtrace_scan_short", lb_ws);
-    });
+    };
+    return a.next_value ? dispatch_scan<VtraceOp, VtraceArgs>(vdt, cdt, go) : dispatch_scan<VtraceShiftedOp, VtraceArgs>(vdt, cdt, go);
 }

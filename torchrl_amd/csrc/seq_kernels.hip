@@ -28,8 +28,8 @@ template <typename TS, typename TG>
 __global__ __launch_bounds__(kSeqThreads) void gae_seq_kernel(GaeArgs a) {
     using TC = typename Promote<TS, TG>::type;
     const TS *__restrict__ r = (const TS *)a.reward;
-    const TS *__restrict__ v = (const TS *)a.value;
-    const TS *__restrict__ nv = (const TS *)a.next_value;
+    const TS *v = (const TS *)a.value;
+    const TS *nv = (const TS *)a.next_value;
     const u8 *__restrict__ d = a.done;
     const u8 *__restrict__ tm = a.terminated;
     const TG *__restrict__ gt = (const TG *)a.gamma_t;
@@ -42,6 +42,10 @@ __global__ __launch_bounds__(kSeqThreads) void gae_seq_kernel(GaeArgs a) {
     double s = 0.0, ss = 0.0;
     if (idx < a.O * a.I) {
         const i64 o = idx / a.I, i = idx - o * a.I;
+        if (!nv) {  // shifted layout: `value` is the (O, T + 1, I) buffer, the next step's value follows I elements on
+            v += o * a.I;
+            nv = v + a.I;
+        }
         i64 j = (o * a.T + (a.T - 1)) * a.I + i;
         // masks broadcast over the feature dims are read in place: element (o, t) for every i
         const i64 ms = a.mask_bcast ? 1 : a.I;
@@ -152,8 +156,8 @@ __global__ __launch_bounds__(kSeqThreads) void vtrace_seq_kernel(VtraceArgs a) {
     using TC = typename Promote<TS, TG>::type;
     const TS *__restrict__ lp = (const TS *)a.log_pi;
     const TS *__restrict__ lmu = (const TS *)a.log_mu;
-    const TS *__restrict__ v = (const TS *)a.value;
-    const TS *__restrict__ nv = (const TS *)a.next_value;
+    const TS *v = (const TS *)a.value;
+    const TS *nv = (const TS *)a.next_value;
     const TS *__restrict__ r = (const TS *)a.reward;
     const u8 *__restrict__ d = a.done;
     const u8 *__restrict__ tm = a.terminated;
@@ -166,6 +170,10 @@ __global__ __launch_bounds__(kSeqThreads) void vtrace_seq_kernel(VtraceArgs a) {
     const i64 idx = (i64)blockIdx.x * kSeqThreads + threadIdx.x;
     if (idx >= a.O * a.I) return;
     const i64 o = idx / a.I, i = idx - o * a.I;
+    if (!nv) {  // shifted layout (see gae_seq_kernel)
+        v += o * a.I;
+        nv = v + a.I;
+    }
     i64 j = (o * a.T + (a.T - 1)) * a.I + i;
     const i64 ms = a.mask_bcast ? 1 : a.I;
     i64 mj = a.mask_bcast ? o * a.T + (a.T - 1) : j;

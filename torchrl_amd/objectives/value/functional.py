@@ -216,6 +216,28 @@ def _val(t: torch.Tensor, dtype, device=None) -> torch.Tensor:
     return t.contiguous()
 
 
+def _shifted_pair(state_value: torch.Tensor, next_state_value: torch.Tensor, shape, time_dim: int, vdt, grads: bool) -> bool:
+    """True when ``state_value`` / ``next_state_value`` are the ``[0, T)`` / ``[1, T + 1)`` time windows of ONE
+    contiguous ``[*B, T + 1, *F]`` buffer with ``prod(F) == 1`` -- what the estimators' ``shifted=True`` single call
+    of the value network yields (reference: advantages.py:440-490).  The kernels then read that buffer in place
+    (include/trl_value.h: ``next_state_value == NULL``), the value bytes once, instead of two copies of it."""
+    sv, nsv = state_value, next_state_value
+    if grads or sv.dtype != vdt or nsv.dtype != vdt or sv.device != nsv.device:
+        return False
+    nd = len(shape)
+    td = time_dim if time_dim >= 0 else nd + time_dim
+    if math.prod(shape[td + 1:]) != 1 or math.prod(shape) == 0 or sv.stride() != nsv.stride():
+        return False
+    if sv.untyped_storage().data_ptr() != nsv.untyped_storage().data_ptr() or nsv.storage_offset() != sv.storage_offset() + sv.stride(td):
+        return False
+    want = 1
+    for d in range(td, -1, -1):  # contiguous strides of the [*B, T + 1] buffer (extent-1 dims are free)
+        if shape[d] != 1 and sv.stride(d) != want:
+            return False
+        want *= shape[d] + 1 if d == td else shape[d]
+    return True
+
+
 def _mask(m: torch.Tensor, shape, device=None) -> torch.Tensor:
     if m.dtype != torch.bool:
         m = m != 0
@@ -296,7 +318,7 @@ class _GaeCall:
     out_dtype: torch.dtype
     reward: torch.Tensor
     value: torch.Tensor
-    next_value: torch.Tensor
+    next_value: Optional[torch.Tensor]  # None: `value` is a window of the shifted (O, T + 1) buffer (_shifted_pair)
     done: torch.Tensor
     terminated: torch.Tensor
     gamma_t: Optional[torch.Tensor]
@@ -339,10 +361,13 @@ def _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, term
         cdt = torch.promote_types(g_dt, lg_dt)
     if cdt not in _DT:
         raise NotImplementedError(f"gamma / lmbda dtype {cdt} is not supported (float32 / float64 only)")
-    d8, t8, bcast = _masks(done, terminated, shape, time_dim, dev, _needs_grad(state_value, next_state_value, reward))
+    grads = _needs_grad(state_value, next_state_value, reward)
+    d8, t8, bcast = _masks(done, terminated, shape, time_dim, dev, grads)
+    shifted = _shifted_pair(state_value, next_state_value, shape, time_dim, vdt, grads)
     return _GaeCall(
         shape=shape, O=O, T=T, I=I, vdt=vdt, cdt=cdt, out_dtype=next_state_value.dtype,
-        reward=_val(reward, vdt, dev), value=_val(state_value, vdt, dev), next_value=_val(next_state_value, vdt, dev),
+        reward=_val(reward, vdt, dev), value=state_value.detach() if shifted else _val(state_value, vdt, dev),
+        next_value=None if shifted else _val(next_state_value, vdt, dev),
         done=d8, terminated=t8, gamma_t=gamma_t, lg_t=lg_t, gamma=g_val, lmbda=l_val, lg=lg_val, mask_bcast=bcast,
     )
 
@@ -424,8 +449,8 @@ def _time_major(c):
 
 def _launch_gae(c: _GaeCall, want_stats: bool = False, algo: int = ALGO_AUTO, out=None):
     lib = _extension.get_lib()
-    _require_hip(c.next_value)
-    dev = c.next_value.device
+    _require_hip(c.reward)
+    dev = c.reward.device
     if out is None and _wants_time_major(c, algo):
         c2, back = _time_major(c)
         adv, vt, stats = _launch_gae(c2, want_stats, algo)
@@ -458,8 +483,8 @@ def _launch_gae_normalize(c: _GaeCall, eps: float, algo: int = ALGO_AUTO, out=No
     ``exchange`` (:class:`StatsExchange`): the batch is sharded over its ranks; the moments are
     summed across GPUs inside the launch (trl_gae_normalize_xchg_fwd)."""
     lib = _extension.get_lib()
-    _require_hip(c.next_value)
-    dev = c.next_value.device
+    _require_hip(c.reward)
+    dev = c.reward.device
     if out is None and _wants_time_major(c, algo):
         c2, back = _time_major(c)
         adv, vt, stats = _launch_gae_normalize(c2, eps, algo, None, want_stats, exchange)
@@ -740,7 +765,7 @@ def prepare_gae_step(call: _GaeCall, eps: Optional[float] = None, *, normalize: 
     ``exchange`` (:class:`StatsExchange`) with ``normalize=True``: ``trl_gae_normalize_xchg_fwd`` -- the
     moments are summed across the exchange's ranks inside the launch."""
     lib = _extension.get_lib()
-    _require_hip(c := call.next_value)
+    _require_hip(c := call.reward)
     dev = c.device
     adv = torch.empty(call.shape, dtype=call.vdt, device=dev)
     vt = torch.empty(call.shape, dtype=call.vdt, device=dev)
@@ -952,8 +977,8 @@ def _prepare_td_lambda(gamma, lmbda, next_state_value, reward, done, terminated,
 
 def _launch_td_lambda(c: _TdLambdaCall, out_dtype, algo: int = ALGO_AUTO) -> torch.Tensor:
     lib = _extension.get_lib()
-    _require_hip(c.next_value)
-    dev = c.next_value.device
+    _require_hip(c.reward)
+    dev = c.reward.device
     if c.rolling and _wants_time_major(c, algo):
         c2, back = _time_major(c)
         return back(_launch_td_lambda(c2, out_dtype, algo))
@@ -1102,7 +1127,7 @@ class _VtraceCall:
     log_pi: torch.Tensor
     log_mu: torch.Tensor
     value: torch.Tensor
-    next_value: torch.Tensor
+    next_value: Optional[torch.Tensor]  # None: shifted layout, as in _GaeCall
     reward: torch.Tensor
     done: torch.Tensor
     terminated: torch.Tensor
@@ -1145,18 +1170,20 @@ def _prepare_vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward
     def bc(t):
         return t if tuple(t.shape) == shape else _expand_coef(t, shape, time_dim)
 
-    masks = _masks(done, terminated, shape, time_dim, dev, _needs_grad(log_pi, log_mu, state_value, next_state_value, reward))
+    grads = _needs_grad(log_pi, log_mu, state_value, next_state_value, reward)
+    masks = _masks(done, terminated, shape, time_dim, dev, grads)
+    shifted = _shifted_pair(state_value, next_state_value, shape, time_dim, vdt, grads)
     return _VtraceCall(shape=shape, O=O, T=T, I=I, vdt=vdt, cdt=cdt, log_pi=_val(bc(log_pi), vdt, dev),
-                       log_mu=_val(bc(log_mu), vdt, dev), value=_val(state_value, vdt, dev),
-                       next_value=_val(next_state_value, vdt, dev), reward=_val(reward, vdt, dev),
+                       log_mu=_val(bc(log_mu), vdt, dev), value=state_value.detach() if shifted else _val(state_value, vdt, dev),
+                       next_value=None if shifted else _val(next_state_value, vdt, dev), reward=_val(reward, vdt, dev),
                        done=masks[0], terminated=masks[1], mask_bcast=masks[2], gamma_t=gamma_t,
                        gamma=g_val, rho_thresh=_thresh(rho_thresh), c_thresh=_thresh(c_thresh))
 
 
 def _launch_vtrace(c: _VtraceCall, algo: int = ALGO_AUTO):
     lib = _extension.get_lib()
-    _require_hip(c.next_value)
-    dev = c.next_value.device
+    _require_hip(c.reward)
+    dev = c.reward.device
     if _wants_time_major(c, algo):
         c2, back = _time_major(c)
         adv, vs = _launch_vtrace(c2, algo)
