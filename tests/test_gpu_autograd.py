@@ -151,9 +151,89 @@ def test_vtrace_gradients(shape, dtype, tensor_gamma):
         torch.testing.assert_close(got.double(), w, msg=lambda m, n=name: f"{n}: {m}", **tol)
 
 
-def test_vtrace_grad_to_gamma_raises_loudly():
-    r = torch.randn(3, 8, 1, device=DEV)
-    gam = torch.full((3, 8, 1), 0.9, device=DEV, requires_grad=True)
-    d = torch.zeros(3, 8, 1, dtype=torch.bool, device=DEV)
-    with pytest.raises(NotImplementedError, match="gamma"):
-        F.vtrace_advantage_estimate(gam, r, r, r, r, r, d)
+COEF_FORMS = ["full", "per_step", "one_element"]
+
+
+def _coef(form, shape, lo, hi, seed, dtype):
+    g = torch.Generator().manual_seed(seed)
+    shp = {"full": shape, "per_step": (1, shape[1], 1), "one_element": (1,)}[form]
+    return (lo + (hi - lo) * torch.rand(shp, generator=g, dtype=torch.float64)).to(dtype).to(DEV).requires_grad_(True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", [(16, 32, 1), (3, 2500, 1), (5, 20, 3)], ids=["16x32", "3x2500", "5x20x3"])
+@pytest.mark.parametrize("form", COEF_FORMS)
+def test_gae_gradients_to_gamma_and_lmbda(shape, dtype, form):
+    """grads w.r.t. gamma / lmbda tensors (full shape, broadcast over batch / features, 1 element)."""
+    v, nv, r, done, term, _, wa, wv = _inputs(shape, dtype)
+    gam, lam = _coef(form, shape, 0.9, 1.0, 1, dtype), _coef(form, shape, 0.8, 1.0, 2, dtype)
+    for fn in (F.generalized_advantage_estimate, F.vec_generalized_advantage_estimate):
+        adv, vt = fn(gam, lam, v, nv, r, done, term)
+        loss = (adv * wa).sum() + (vt * wv).sum()
+        got = torch.autograd.grad(loss, (gam, lam, v, nv, r))
+        d = lambda x: x.detach().double().requires_grad_(True)
+        g2, l2, v2, nv2, r2 = d(gam), d(lam), d(v), d(nv), d(r)
+        a2, t2 = torch_gae(g2.expand(shape) if form != "one_element" else g2, (l2 * g2).expand(shape) if form != "one_element" else l2 * g2,
+                           v2, nv2, r2, done, term)
+        want = torch.autograd.grad((a2 * wa.double()).sum() + (t2 * wv.double()).sum(), (g2, l2, v2, nv2, r2))
+        tol = dict(rtol=2e-4, atol=2e-3) if dtype == torch.float32 else dict(rtol=1e-9, atol=1e-8)
+        for name, a, b in zip(("gamma", "lmbda", "v", "nv", "r"), got, want):
+            assert a.shape == b.shape and a.dtype == dtype
+            torch.testing.assert_close(a.double(), b, msg=lambda m, n=name: f"{n}: {m}", **tol)
+    # only lmbda requires grad (gamma a python float)
+    adv, _ = F.generalized_advantage_estimate(0.97, lam, v.detach(), nv.detach(), r.detach(), done, term)
+    (gl,) = torch.autograd.grad((adv * wa).sum(), (lam,))
+    l2 = lam.detach().double().requires_grad_(True)
+    # delta uses gamma rounded to the default dtype, `lmbda * gamma` the python double (functional.py:172-174)
+    a2, _ = torch_gae(float(torch.tensor(0.97)), (l2 * 0.97).expand(shape) if form != "one_element" else l2 * 0.97,
+                      v.detach().double(), nv.detach().double(), r.detach().double(), done, term)
+    (wl,) = torch.autograd.grad((a2 * wa.double()).sum(), (l2,))
+    torch.testing.assert_close(gl.double(), wl, **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", [(16, 32, 1), (3, 2500, 1)], ids=["16x32", "3x2500"])
+@pytest.mark.parametrize("form", ["full", "one_element"])
+def test_td_lambda_gradients_to_gamma_and_lmbda(shape, dtype, form):
+    _, nv, r, done, term, _, wa, _ = _inputs(shape, dtype)
+    gam, lam = _coef(form, shape, 0.9, 1.0, 1, dtype), _coef(form, shape, 0.8, 1.0, 2, dtype)
+    for fn in (F.td_lambda_return_estimate, F.vec_td_lambda_return_estimate):
+        ret = fn(gam, lam, nv, r, done, term)
+        got = torch.autograd.grad((ret * wa).sum(), (gam, lam, nv, r))
+        d = lambda x: x.detach().double().requires_grad_(True)
+        g2, l2, nv2, r2 = d(gam), d(lam), d(nv), d(r)
+        nvm = nv2 * (~term).double()
+        dn = done.double()
+        g = nvm[:, -1]
+        out = []
+        gg, ll = (g2.expand(shape), l2.expand(shape))
+        for t in reversed(range(shape[1])):
+            g = g * (1 - dn[:, t]) + nvm[:, t] * dn[:, t]
+            g = r2[:, t] + gg[:, t] * ((1 - ll[:, t]) * nvm[:, t] + ll[:, t] * g)
+            out.append(g)
+        want = torch.autograd.grad((torch.stack(out[::-1], 1) * wa.double()).sum(), (g2, l2, nv2, r2))
+        tol = dict(rtol=2e-4, atol=2e-3) if dtype == torch.float32 else dict(rtol=1e-9, atol=1e-8)
+        for name, a, b in zip(("gamma", "lmbda", "nv", "r"), got, want):
+            assert a.shape == b.shape and a.dtype == dtype
+            torch.testing.assert_close(a.double(), b, msg=lambda m, n=name: f"{n}: {m}", **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("form", ["full", "one_element"])
+def test_vtrace_gradient_to_gamma(dtype, form):
+    shape = (6, 40, 1)
+    v, nv, r, done, term, _, wa, wv = _inputs(shape, dtype)
+    g = torch.Generator().manual_seed(5)
+    lp = (0.5 * torch.randn(shape, generator=g, dtype=torch.float64)).to(dtype).to(DEV)
+    lm = (0.5 * torch.randn(shape, generator=g, dtype=torch.float64)).to(dtype).to(DEV)
+    gam = _coef(form, shape, 0.9, 1.0, 1, dtype)
+    adv, vs = F.vtrace_advantage_estimate(gam, lp, lm, v, nv, r, done, term)
+    got = torch.autograd.grad((adv * wa).sum() + (vs * wv).sum(), (gam, v, nv, r))
+    d = lambda x: x.detach().double().requires_grad_(True)
+    g2, v2, nv2, r2 = d(gam), d(v), d(nv), d(r)
+    a2, s2 = torch_vtrace(g2.expand(shape), lp.double(), lm.double(), v2, nv2, r2, done, term, 1.0, 1.0)
+    want = torch.autograd.grad((a2 * wa.double()).sum() + (s2 * wv.double()).sum(), (g2, v2, nv2, r2))
+    tol = dict(rtol=2e-4, atol=2e-3) if dtype == torch.float32 else dict(rtol=1e-9, atol=1e-8)
+    for name, a, b in zip(("gamma", "v", "nv", "r"), got, want):
+        assert a.shape == b.shape and a.dtype == dtype
+        torch.testing.assert_close(a.double(), b, msg=lambda m, n=name: f"{n}: {m}", **tol)

@@ -179,7 +179,7 @@ def _scalar_mask_coef(x) -> Tuple[float, torch.dtype]:
     (python number, 0-dim or 1-element tensor)."""
     dt = _mask_coef_dtype(x)
     if isinstance(x, torch.Tensor):
-        val = float(x)  # host read; device scalars synchronise (modules cache host copies)
+        val = float(x.detach())  # host read; device scalars synchronise (modules cache host copies)
         return (val if x.dtype.is_floating_point else _round_to(val, dt)), dt
     return _round_to(float(x), dt), dt
 
@@ -519,8 +519,9 @@ def _launch_gae_normalize(c: _GaeCall, eps: float, algo: int = ALGO_AUTO, out=No
 # backward pass runs on the SAME HIP kernels (trl_gae_fwd with value = next_value = 0 and every step
 # "terminated", which makes delta = gbar' exactly) on flipped inputs with the masks shifted by one
 # step.  Gradients flow to reward / state_value / next_state_value (reference behaviour under
-# differentiable=True, test/test_cost.py:15521-15584); gamma / lmbda tensors that require grad are
-# not supported.  V-trace: _VtraceFunction below (also to log_pi / log_mu).
+# differentiable=True, test/test_cost.py:15521-15584) and to gamma / lmbda tensors that require grad
+# (per-element products of G with the saved outputs; autograd sums them over the broadcast dims).
+# V-trace: _VtraceFunction below (also to log_pi / log_mu / gamma).
 def _adjoint_scan(gbar3: torch.Tensor, done3: torch.Tensor, lg3: Optional[torch.Tensor], lg: float, cdt) -> torch.Tensor:
     """G (O,T,I) from gbar (O,T,I): G_t = gbar_t + (lg_{t-1} * (1-done_{t-1})) * G_{t-1}."""
     O, T, I = gbar3.shape
@@ -540,16 +541,48 @@ def _adjoint_scan(gbar3: torch.Tensor, done3: torch.Tensor, lg3: Optional[torch.
     return G.flip(1)
 
 
+def _coef_leaf(x, shape, time_dim):
+    """A gamma / lmbda tensor that requires grad, as a differentiable view of the inputs' shape (torch's autograd
+    then sums the per-element gradient the Functions below return over the broadcast dims); None otherwise."""
+    if not (isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled()):
+        return None
+    if x.numel() == 1:
+        return x.reshape(()).expand(shape)
+    return x if tuple(x.shape) == tuple(shape) else _expand_coef(x, shape, time_dim)
+
+
+def _coef_value(x, c, dt, time_dim) -> torch.Tensor:
+    """Detached value of a coefficient in dtype ``dt``: 0-dim, or the canonical (O, T, I) view."""
+    dev = c.reward.device
+    if isinstance(x, torch.Tensor):
+        x = x.detach().to(device=dev, dtype=dt)
+        if x.numel() == 1:
+            return x.reshape(())
+        return (x if tuple(x.shape) == tuple(c.shape) else _expand_coef(x, c.shape, time_dim)).reshape(c.O, c.T, c.I)
+    return torch.full((), float(x), dtype=dt, device=dev)
+
+
+def _coef_grad(g3, leaf, c):
+    return None if leaf is None else g3.reshape(c.shape).to(leaf.dtype)
+
+
 class _GaeFunction(torch.autograd.Function):
+    """``coefs = (gamma, lmbda, time_dim)`` as the caller passed them; ``gamma_e`` / ``lmbda_e`` are their
+    differentiable full-shape views (:func:`_coef_leaf`) or None."""
+
     @staticmethod
-    def forward(ctx, state_value, next_state_value, reward, call, normalize_eps):
+    def forward(ctx, state_value, next_state_value, reward, gamma_e, lmbda_e, call, normalize_eps, coefs):
         if normalize_eps is None:
             adv, vt, _ = _launch_gae(call)
         else:
             raise NotImplementedError("differentiable normalised GAE: normalise the differentiable advantage with torch ops")
         ctx.call = call
+        ctx.coefs = coefs
         ctx.in_dtypes = (state_value.dtype, next_state_value.dtype, reward.dtype)
         ctx.in_shapes = (state_value.shape, next_state_value.shape, reward.shape)
+        ctx.leaves = (gamma_e, lmbda_e)
+        if gamma_e is not None or lmbda_e is not None:
+            ctx.save_for_backward(adv)
         return adv, vt
 
     @staticmethod
@@ -567,16 +600,33 @@ class _GaeFunction(torch.autograd.Function):
         nt = (1 - c.terminated.view(shp3)).to(dt)
         g_coef = c.gamma_t.view(shp3).to(dt) * nt if c.gamma_t is not None else nt * c.gamma
         outs = (gv - G, G * g_coef, G)
-        return tuple(o.to(d).view(s) for o, d, s in zip(outs, ctx.in_dtypes, ctx.in_shapes)) + (None, None)
+        d_gamma = d_lmbda = None
+        gamma_e, lmbda_e = ctx.leaves
+        if gamma_e is not None or lmbda_e is not None:
+            # A_t = delta_t + (lmbda_t gamma_t (1 - done_t)) A_{t+1},  delta_t = r_t + gamma_t (1 - terminated_t) v'_t - v_t
+            (adv,) = ctx.saved_tensors
+            A = adv.view(shp3).to(dt)
+            d_lg = G * (1 - done3).to(dt) * torch.cat([A[:, 1:], torch.zeros_like(A[:, :1])], 1)
+            gamma, lmbda, time_dim = ctx.coefs
+            if gamma_e is not None:
+                d_gamma = _coef_grad(G * nt * c.next_value.view(shp3).to(dt) + d_lg * _coef_value(lmbda, c, dt, time_dim), gamma_e, c)
+            if lmbda_e is not None:
+                d_lmbda = _coef_grad(d_lg * _coef_value(gamma, c, dt, time_dim), lmbda_e, c)
+        return tuple(o.to(d).view(s) for o, d, s in zip(outs, ctx.in_dtypes, ctx.in_shapes)) + (d_gamma, d_lmbda, None, None, None)
 
 
 class _TdLambdaFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, next_state_value, reward, call, out_dtype):
+    def forward(ctx, next_state_value, reward, gamma_e, lmbda_e, call, out_dtype, coefs):
         ctx.call = call
+        ctx.coefs = coefs
         ctx.in_dtypes = (next_state_value.dtype, reward.dtype)
         ctx.in_shapes = (next_state_value.shape, reward.shape)
-        return _launch_td_lambda(call, out_dtype)
+        ctx.leaves = (gamma_e, lmbda_e)
+        ret = _launch_td_lambda(call, out_dtype)
+        if gamma_e is not None or lmbda_e is not None:
+            ctx.save_for_backward(ret)
+        return ret
 
     @staticmethod
     def backward(ctx, g_ret):
@@ -598,9 +648,21 @@ class _TdLambdaFunction(torch.autograd.Function):
         d_nvm = G * gam * ((1 - lam) + lam * dn)
         last = (G * gam * lam * (1 - dn))[:, -1]
         d_nvm = torch.cat([d_nvm[:, :-1], (d_nvm[:, -1] + last).unsqueeze(1)], 1)
-        d_nv = d_nvm * (1 - c.terminated.view(shp3)).to(dt)
+        nt = (1 - c.terminated.view(shp3)).to(dt)
+        d_nv = d_nvm * nt
         outs = (d_nv, G)
-        return tuple(o.to(d).view(s) for o, d, s in zip(outs, ctx.in_dtypes, ctx.in_shapes)) + (None, None)
+        d_gamma = d_lmbda = None
+        gamma_e, lmbda_e = ctx.leaves
+        if gamma_e is not None or lmbda_e is not None:
+            (ret,) = ctx.saved_tensors
+            R = ret.view(shp3).to(dt)
+            nvm = c.next_value.view(shp3).to(dt) * nt
+            g1 = torch.cat([R[:, 1:], nvm[:, -1:]], 1) * (1 - dn) + nvm * dn   # what lmbda_t multiplies at step t
+            if gamma_e is not None:
+                d_gamma = _coef_grad(G * ((1 - lam) * nvm + lam * g1), gamma_e, c)
+            if lmbda_e is not None:
+                d_lmbda = _coef_grad(G * gam * (g1 - nvm), lmbda_e, c)
+        return tuple(o.to(d).view(s) for o, d, s in zip(outs, ctx.in_dtypes, ctx.in_shapes)) + (d_gamma, d_lmbda, None, None, None)
 
 
 class _VtraceFunction(torch.autograd.Function):
@@ -608,9 +670,10 @@ class _VtraceFunction(torch.autograd.Function):
     trl_vtrace_fwd; backward = elementwise torch ops + ONE adjoint scan on the HIP scan kernels."""
 
     @staticmethod
-    def forward(ctx, log_pi, log_mu, state_value, next_state_value, reward, call):
+    def forward(ctx, log_pi, log_mu, state_value, next_state_value, reward, gamma_e, call):
         adv, vs = _launch_vtrace(call)
         ctx.call = call
+        ctx.gamma_e = gamma_e
         ctx.ins = tuple((t.dtype, t.shape) for t in (log_pi, log_mu, state_value, next_state_value, reward))
         ctx.save_for_backward(vs)
         return adv, vs
@@ -659,7 +722,10 @@ class _VtraceFunction(torch.autograd.Function):
         for o, (d, sh) in zip(outs, ctx.ins):
             g = back(o, d, tuple(sh))
             res.append(g.reshape(sh) if g.numel() == math.prod(sh) else g)
-        return tuple(res) + (None,)
+        d_gamma = None
+        if ctx.gamma_e is not None:  # gamma enters as gamma * not_terminated (delta, advantage) and gamma * not_done (trace)
+            d_gamma = _coef_grad(nt * rb * (A * vsp + X * nv) + nd * X * x_next * cb, ctx.gamma_e, c)
+        return tuple(res) + (d_gamma, None)
 
 
 def _geom_series_like(t: torch.Tensor, r, thr: float) -> torch.Tensor:
@@ -675,12 +741,6 @@ def _geom_series_like(t: torch.Tensor, r, thr: float) -> torch.Tensor:
     ratios = torch.full_like(t[:lim], r)
     ratios[0] = 1.0
     return ratios.cumprod(0).unsqueeze(-1)   # cumulative products, as the reference forms them (not r**k)
-
-
-def _no_coef_grad(name, *coefs):
-    for x in coefs:
-        if isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError(f"torchrl_amd: {name}: gradients w.r.t. gamma / lmbda tensors are not implemented")
 
 
 def generalized_advantage_estimate(
@@ -701,8 +761,8 @@ def generalized_advantage_estimate(
     """
     call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
     if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
-        _no_coef_grad("generalized_advantage_estimate", gamma, lmbda)
-        return _GaeFunction.apply(state_value, next_state_value, reward, call, None)
+        return _GaeFunction.apply(state_value, next_state_value, reward, _coef_leaf(gamma, call.shape, time_dim),
+                                  _coef_leaf(lmbda, call.shape, time_dim), call, None, (gamma, lmbda, time_dim))
     adv, vt, _ = _launch_gae(call)
     return adv, vt
 
@@ -723,8 +783,8 @@ def vec_generalized_advantage_estimate(
     call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
     call.out_dtype = state_value.dtype  # functional.py:314
     if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
-        _no_coef_grad("vec_generalized_advantage_estimate", gamma, lmbda)
-        return _GaeFunction.apply(state_value, next_state_value, reward, call, None)
+        return _GaeFunction.apply(state_value, next_state_value, reward, _coef_leaf(gamma, call.shape, time_dim),
+                                  _coef_leaf(lmbda, call.shape, time_dim), call, None, (gamma, lmbda, time_dim))
     adv, vt, _ = _launch_gae(call)
     return adv, vt
 
@@ -806,8 +866,8 @@ def gae_normalized(gamma, lmbda, state_value, next_state_value, reward, done, te
     call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
     if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
         # differentiable path: GAE through the autograd function, normalisation as the reference's torch ops
-        _no_coef_grad("gae_normalized", gamma, lmbda)
-        adv, vt = _GaeFunction.apply(state_value, next_state_value, reward, call, None)
+        adv, vt = _GaeFunction.apply(state_value, next_state_value, reward, _coef_leaf(gamma, call.shape, time_dim),
+                                     _coef_leaf(lmbda, call.shape, time_dim), call, None, (gamma, lmbda, time_dim))
         return (adv - adv.mean()) / adv.std().clamp_min(eps), vt
     dist = torch.distributed
     if exchange is not None:
@@ -935,7 +995,7 @@ def _td_coef(x, done_shape, vdt, name):
         if x.numel() != 1:
             raise RuntimeError(
                 f"{name} must be a scalar or a tensor with the shape of the inputs {tuple(done_shape)}, got {tuple(x.shape)}")
-        x = float(x)
+        x = float(x.detach())
     return None, _round_to(float(x), vdt), vdt
 
 
@@ -1014,8 +1074,9 @@ def td_lambda_return_estimate(
     """
     call = _prepare_td_lambda(gamma, lmbda, next_state_value, reward, done, terminated, rolling_gamma, time_dim)
     if _needs_grad(next_state_value, reward, gamma, lmbda):
-        _no_coef_grad("td_lambda_return_estimate", gamma, lmbda)
-        return _TdLambdaFunction.apply(next_state_value, reward, call, next_state_value.dtype)
+        return _TdLambdaFunction.apply(next_state_value, reward, _coef_leaf(gamma, call.shape, time_dim),
+                                       _coef_leaf(lmbda, call.shape, time_dim), call, next_state_value.dtype,
+                                       (gamma, lmbda, time_dim))
     return _launch_td_lambda(call, next_state_value.dtype)
 
 
@@ -1062,8 +1123,9 @@ def vec_td_lambda_return_estimate(
         rolling_gamma = None  # the reference's fast path ignores it (functional.py:1101-1110)
     call = _prepare_td_lambda(gamma, lmbda, next_state_value, reward, done, terminated, rolling_gamma, time_dim, vec=True)
     if _needs_grad(next_state_value, reward, gamma, lmbda):
-        _no_coef_grad("vec_td_lambda_return_estimate", gamma, lmbda)
-        return _TdLambdaFunction.apply(next_state_value, reward, call, next_state_value.dtype)
+        return _TdLambdaFunction.apply(next_state_value, reward, _coef_leaf(gamma, call.shape, time_dim),
+                                       _coef_leaf(lmbda, call.shape, time_dim), call, next_state_value.dtype,
+                                       (gamma, lmbda, time_dim))
     return _launch_td_lambda(call, next_state_value.dtype)
 
 
@@ -1224,8 +1286,8 @@ def vtrace_advantage_estimate(
     call = _prepare_vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward, done, terminated,
                            rho_thresh, c_thresh, time_dim)
     if _needs_grad(log_pi, log_mu, state_value, next_state_value, reward, gamma):
-        _no_coef_grad("vtrace_advantage_estimate", gamma)
-        return _VtraceFunction.apply(log_pi, log_mu, state_value, next_state_value, reward, call)
+        return _VtraceFunction.apply(log_pi, log_mu, state_value, next_state_value, reward,
+                                     _coef_leaf(gamma, call.shape, time_dim), call)
     return _launch_vtrace(call)
 
 
