@@ -58,7 +58,7 @@ enum {
                           bit-exact at done boundaries */
     TRL_ALGO_FUSED = 3 /* trl_gae_normalize_fwd only: single persistent launch, advantages kept in
                           registers across an in-launch all-gather of the fp64 moments */,
-    TRL_ALGO_LOCKSTEP = 4 /* 2 <= I <= 8 feature elements per step, any T: a lane owns one time step, the I
+    TRL_ALGO_LOCKSTEP = 4 /* 2 <= I <= 31 feature elements per step (groups of <= 8), any T: a lane owns one time step, the I
                           recurrences are scanned in lock step (no LDS transpose); same parity as SCAN */
 };
 

@@ -38,7 +38,7 @@ def algos(call):
     """SEQ always; SCAN when the family supports the shape (I == 1, or whole outer rows fit a chunk)."""
     chunk = 256 * (4 if call.vdt == torch.float32 else 2)
     out = [SEQ, SCAN] if (call.I == 1 or call.T * call.I <= chunk) else [SEQ]
-    if 2 <= call.I <= 8 and not (call.vdt == torch.float32 and call.cdt == torch.float64):
+    if 2 <= call.I <= 31 and not (call.vdt == torch.float32 and call.cdt == torch.float64):
         out.append(LOCKSTEP)  # a lane per time step, the I recurrences in lock step: any T
     return out
 
@@ -442,16 +442,29 @@ def test_broadcast_masks_read_in_place(shape, time_dim, dtype):
 
 
 LONG_IL = [((16, 400, 5), -2), ((3, 2000, 3, 2), 1), ((64, 1000, 5, 1), -3), ((5, 300, 4), -2), ((7, 257, 2), -2), ((2, 5000, 8), -2),
-           ((300, 256, 7), -2), ((40, 700, 12), -2)]
+           ((300, 256, 7), -2), ((40, 700, 12), -2), ((6, 300, 9), -2), ((3, 130, 4, 4), 1), ((5, 260, 17), -2), ((2, 600, 31), -2),
+           ((70, 40, 31), -2)]
+
+
+@pytest.mark.parametrize("shape", [(16, 400, 5), (40, 700, 12)], ids=["16x400x5", "40x700x12"])
+def test_long_rows_few_features_fp32_values_fp64_gamma(shape):
+    """The one dtype pair the lock-step kernels do not instantiate: re-laid out time-major onto the I == 1 kernels."""
+    r, v, nv, done, term, gam, lp, lm = _rand_inputs(shape, torch.float32, seed=32, p_term=0.01, p_trunc=0.01)
+    gam = gam.double()
+    oadv, ovt = O.gae(gam, 0.9, v, nv, r, done, term)
+    adv, vt = F.generalized_advantage_estimate(cu(gam), 0.9, cu(v), cu(nv), cu(r), cu(done), cu(term))
+    assert F.last_kernel() in ("gae_scan_short", "gae_scan_long") and adv.is_contiguous()
+    torch.testing.assert_close(adv.cpu(), oadv, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(vt.cpu(), ovt, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("shape,time_dim", LONG_IL, ids=["x".join(map(str, s)) for s, _ in LONG_IL])
 @pytest.mark.parametrize("bcast", [False, True], ids=["full_masks", "bcast_masks"])
 def test_long_rows_with_few_features(shape, time_dim, dtype, bcast):
-    """T * I beyond one chunk of the LDS-transposing kernel: 2 <= I <= 8 takes the lock-step kernels (a lane per
-    time step, chunk loop with I carries), 8 < I < 32 with few rows is re-laid out time-major onto the I == 1
-    kernels -- never the uncoalesced SEQ walk; all three estimators and the normalised GAE, SCAN-family tolerance."""
+    """T * I beyond one chunk of the LDS-transposing kernel: 2 <= I <= 31 takes the lock-step kernels (a lane per
+    time step, chunk loop with I carries; groups of <= 8 feature elements beyond 8) -- never the uncoalesced SEQ walk
+    on few rows; all three estimators and the normalised GAE, SCAN-family tolerance."""
     r, v, nv, done, term, gam, lp, lm = _rand_inputs(shape, dtype, seed=31, p_term=0.01, p_trunc=0.01)
     if bcast:
         td = time_dim if time_dim < 0 else time_dim - len(shape)
@@ -479,3 +492,19 @@ def test_long_rows_with_few_features(shape, time_dim, dtype, bcast):
     adv_seq, _, _ = F._launch_gae(gcall, algo=SEQ)
     assert F.last_kernel() == "gae_seq"
     check(adv_seq, oadv, True)
+    # and the lock-step family on request, whatever AUTO picked (I <= 31: groups of <= 8 feature elements)
+    if gcall.I <= 31 and not (gcall.vdt == torch.float32 and gcall.cdt == torch.float64):
+        adv_ls, vt_ls, st = F._launch_gae(gcall, want_stats=True, algo=LOCKSTEP)
+        assert F.last_kernel() == "gae_scan_lockstep"
+        check(adv_ls, oadv, False, done)
+        check(vt_ls, ovt, False, done)
+        a64 = adv_ls.double()
+        torch.testing.assert_close(st, torch.stack([torch.tensor(float(a64.numel()), device=DEV), a64.sum(), (a64 * a64).sum()]),
+                                   rtol=1e-12, atol=1e-9)
+        tcall = F._prepare_td_lambda(0.97, 0.9, cu(nv), cu(r), dd, tt, None, time_dim)
+        check(F._launch_td_lambda(tcall, dtype, algo=LOCKSTEP), oret, False)
+        vcall = F._prepare_vtrace(cu(gam), cu(lp), cu(lm), cu(v), cu(nv), cu(r), dd, tt, 1.0, 1.0, time_dim)
+        va, vs = F._launch_vtrace(vcall, algo=LOCKSTEP)
+        assert F.last_kernel() == "vtrace_scan_lockstep"
+        check(va, ova, False)
+        check(vs, ovs, False)

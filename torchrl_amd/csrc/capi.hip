@@ -87,6 +87,12 @@ static bool prefer_lockstep(int val_dtype, int coef_dtype, int64_t T, int64_t I)
     return R * T * I * 100 < chunk * 95;
 }
 
+// Outer rows too long for the transposing kernel, 9 <= I <= 31: lock-step groups or the SEQ walk (coalesced only
+// over i, but every (o, i) row is a lane).  Measured fp32 (SEQ / LOCKSTEP us): [64x1000x16] 381 / 20, [1024x300x16]
+// 145 / 62, [4096x300x16] 281 / 218, [1024x100x31] 68 / 65, [8192x100x16] 117 / 146, [16384x64x31] 360 / 817:
+// SEQ once there are enough rows to hide its per-step latency.
+static bool lockstep_over_seq(int64_t O, int64_t I) { return I <= 8 || O * I < 131072; }
+
 // error reporting for the other translation units' entry points (xchg_kernels.hip)
 int trl_internal_fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -147,10 +153,10 @@ int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward,
         res = launch_gae_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
         return fail(TRL_ERR_UNSUPPORTED, "trl_gae_fwd: SCAN family does not support this shape (needs I == 1)");
-    if (res.status == TRL_ERR_UNSUPPORTED && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_LOCKSTEP))
+    if (res.status == TRL_ERR_UNSUPPORTED && ((algo == TRL_ALGO_AUTO && lockstep_over_seq(O, I)) || algo == TRL_ALGO_LOCKSTEP))
         res = launch_gae_lockstep(s, val_dtype, coef_dtype, a);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_LOCKSTEP)
-        return fail(TRL_ERR_UNSUPPORTED, "trl_gae_fwd: LOCKSTEP family needs 2 <= I <= 8 (and not fp32 values with fp64 coefficients)");
+        return fail(TRL_ERR_UNSUPPORTED, "trl_gae_fwd: LOCKSTEP family needs 2 <= I <= 31 (and not fp32 values with fp64 coefficients)");
     if (res.status == TRL_ERR_UNSUPPORTED) res = launch_gae_seq(s, val_dtype, coef_dtype, a);
     if (res.status != 0) return fail(res.status, "trl_gae_fwd: launch rejected (grid too large?)");
     if (int rc = check_launch("trl_gae_fwd")) return rc;
@@ -187,10 +193,10 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype, const void *r
         res = launch_td_lambda_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
         return fail(TRL_ERR_UNSUPPORTED, "trl_td_lambda_fwd: SCAN family does not support this case (needs I == 1, rolling gamma)");
-    if (res.status == TRL_ERR_UNSUPPORTED && rolling_gamma && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_LOCKSTEP))
+    if (res.status == TRL_ERR_UNSUPPORTED && rolling_gamma && ((algo == TRL_ALGO_AUTO && lockstep_over_seq(O, I)) || algo == TRL_ALGO_LOCKSTEP))
         res = launch_td_lambda_lockstep(s, val_dtype, coef_dtype, a);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_LOCKSTEP)
-        return fail(TRL_ERR_UNSUPPORTED, "trl_td_lambda_fwd: LOCKSTEP family needs 2 <= I <= 8 (not fp32 values with fp64 coefficients), rolling gamma");
+        return fail(TRL_ERR_UNSUPPORTED, "trl_td_lambda_fwd: LOCKSTEP family needs 2 <= I <= 31 (not fp32 values with fp64 coefficients), rolling gamma");
     if (res.status == TRL_ERR_UNSUPPORTED) res = launch_td_lambda_seq(s, val_dtype, coef_dtype, a, rolling_gamma);
     if (res.status != 0) return fail(res.status, "trl_td_lambda_fwd: launch rejected (grid too large?)");
     if (int rc = check_launch("trl_td_lambda_fwd")) return rc;
@@ -221,10 +227,10 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_
         res = launch_vtrace_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
         return fail(TRL_ERR_UNSUPPORTED, "trl_vtrace_fwd: SCAN family does not support this shape (needs I == 1)");
-    if (res.status == TRL_ERR_UNSUPPORTED && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_LOCKSTEP))
+    if (res.status == TRL_ERR_UNSUPPORTED && ((algo == TRL_ALGO_AUTO && lockstep_over_seq(O, I)) || algo == TRL_ALGO_LOCKSTEP))
         res = launch_vtrace_lockstep(s, val_dtype, coef_dtype, a);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_LOCKSTEP)
-        return fail(TRL_ERR_UNSUPPORTED, "trl_vtrace_fwd: LOCKSTEP family needs 2 <= I <= 8 (and not fp32 values with fp64 coefficients)");
+        return fail(TRL_ERR_UNSUPPORTED, "trl_vtrace_fwd: LOCKSTEP family needs 2 <= I <= 31 (and not fp32 values with fp64 coefficients)");
     if (res.status == TRL_ERR_UNSUPPORTED) res = launch_vtrace_seq(s, val_dtype, coef_dtype, a);
     if (res.status != 0) return fail(res.status, "trl_vtrace_fwd: launch rejected (grid too large?)");
     if (int rc = check_launch("trl_vtrace_fwd")) return rc;

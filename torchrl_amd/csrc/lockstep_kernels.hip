@@ -1,4 +1,4 @@
-// Lock-step scan kernels for a FEW feature elements per time step (2 <= I <= 8), any T.
+// Lock-step scan kernels for a FEW feature elements per time step (2 <= I <= 31), any T.
 //
 // Element (o, t, i) sits at (o*T + t)*I + i: the I scans of an outer row are interleaved in memory (multi-agent
 // rollouts [E, T, A, 1], torchrl's MAPPO / IPPO configs).  Here a LANE owns one time step and its I feature elements
@@ -8,7 +8,10 @@
 //   * the I recurrences advance in LOCK STEP: the suffix scan over the lanes (DPP row shifts, two cross-row shuffles,
 //     wave aggregates through LDS) composes I independent affine maps per move, and the step that follows (t, i)
 //     is always element i of the next lane;
-//   * masks that are shared by the I elements of a step (mask_bcast) are one byte per lane.
+//   * masks that are shared by the I elements of a step (mask_bcast) are one byte per lane;
+//   * 9 <= I <= 31: the feature elements are split into ceil(I / 8) groups of NI = ceil(I / groups) (blockIdx.y; the last
+//     group may hold fewer), each group an independent lock-step scan that reads its NI-element slice of every step --
+//     the groups of a step share cache lines, and with a grid that is a multiple of 8 they run on the same XCD.
 // Short outer rows (T <= 256): a chunk is R = 256 / T whole rows, blocks walk chunks grid-stride.  Long rows: a block
 // owns outer rows and walks each row's 256-step chunks from the end, the I carries (and V-trace's I next
 // state_values) in registers.  Same arithmetic contract as the SCAN family: every lane replays its step with the
@@ -23,6 +26,7 @@ constexpr int kLsThreads = 256;
 
 struct LsGeom {
     i64 O, T;
+    int I;               // feature elements per step in memory (>= Op::V when they are split into groups)
     int rows_per_chunk;  // short rows: whole outer rows per chunk; 0: long rows
     i64 nchunks;         // short rows: chunks in total; long rows: chunks per row
 };
@@ -107,8 +111,12 @@ __device__ __forceinline__ void ls_chunk(const Op &op, LsShared<Op> &sh, int buf
     emit(xs, x_in, vn);
 }
 
-template <class Op>
-__device__ __forceinline__ void ls_load(const typename Op::Args &args, i64 step_index, bool valid, typename Op::Raw &raw) {
+// i0 / ne: first feature element of the block's group and how many the group holds (ne <= Op::V; the rest read as 0,
+// which every estimator maps to 0 outputs, and are not stored)
+// VEC: every group is full and its slice of a step is naturally aligned -> one vector load / store per tensor
+template <class Op, bool VEC>
+__device__ __forceinline__ void ls_load(const typename Op::Args &args, i64 step_index, int I, int i0, int ne, bool valid,
+                                        typename Op::Raw &raw) {
     constexpr int NI = Op::V;
     Op::for_each_input(args, raw, [&](auto *base, auto &arr) {
         typedef typename std::remove_reference<decltype(arr[0])>::type E;
@@ -118,12 +126,12 @@ __device__ __forceinline__ void ls_load(const typename Op::Args &args, i64 step_
 #pragma unroll
             for (int e = 0; e < NI; ++e) arr[e] = m;
         } else {
-            load_n<false>(base, step_index * NI, valid ? NI : 0, arr);
+            load_n<VEC>(base, step_index * I + i0, valid ? ne : 0, arr);
         }
     });
 }
 
-template <class Op>
+template <class Op, bool VEC>
 __global__ __launch_bounds__(kLsThreads) void lockstep_kernel(typename Op::Args args, LsGeom geo, double *partials) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
@@ -133,16 +141,18 @@ __global__ __launch_bounds__(kLsThreads) void lockstep_kernel(typename Op::Args 
     __shared__ double red[2 * kLsThreads / kWave];
     double s = 0.0, ss = 0.0;
     int buf = 0;
+    const int I = geo.I, i0 = (int)blockIdx.y * NI;
+    const int ne = I - i0 < NI ? I - i0 : NI;
     auto run = [&](i64 step_index, bool valid, bool row_end, TC (&Xc)[NI], TS (&Xv)[NI]) {
         typename Op::Raw raw;
-        ls_load<Op>(args, step_index, valid, raw);
+        ls_load<Op, VEC>(args, step_index, I, i0, ne, valid, raw);
         Op op;
         op.prepare(args, raw);
         ls_chunk<Op>(op, sh, buf, valid, row_end, Xc, Xv, [&](const TC(&xs)[NI], const TC(&x_in)[NI], const TS(&vn)[NI]) {
             TO o0[NI], o1[NI];
             op.outputs_ls(valid, xs, row_end, x_in, vn, o0, o1, s, ss);
-            store_n<false>(Op::out_ptr(args, 0), step_index * NI, valid ? NI : 0, o0);
-            if (Op::kNumOut > 1) store_n<false>(Op::out_ptr(args, 1), step_index * NI, valid ? NI : 0, o1);
+            store_n<VEC>(Op::out_ptr(args, 0), step_index * I + i0, valid ? ne : 0, o0);
+            if (Op::kNumOut > 1) store_n<VEC>(Op::out_ptr(args, 1), step_index * I + i0, valid ? ne : 0, o1);
         });
         buf ^= 1;
     };
@@ -175,8 +185,9 @@ __global__ __launch_bounds__(kLsThreads) void lockstep_kernel(typename Op::Args 
     if (partials) {
         block_sum2<kLsThreads>(s, ss, red);
         if (threadIdx.x == 0) {
-            partials[2 * (i64)blockIdx.x] = s;
-            partials[2 * (i64)blockIdx.x + 1] = ss;
+            const i64 b = (i64)blockIdx.y * gridDim.x + blockIdx.x;
+            partials[2 * b] = s;
+            partials[2 * b + 1] = ss;
         }
     }
 }
@@ -189,10 +200,11 @@ int ls_cus() {
 }
 
 template <template <typename, typename, int> class OpT, typename TS, typename TG, int NI, class Args>
-LaunchResult launch_ls(hipStream_t s, const Args &a, double *partials, const char *name) {
+LaunchResult launch_ls(hipStream_t s, const Args &a, bool aligned, double *partials, const char *name) {
     typedef OpT<TS, TG, NI> Op;
     static const int cus = ls_cus();
-    LsGeom geo{a.O, a.T, 0, 0};
+    LsGeom geo{a.O, a.T, (int)a.I, 0, 0};
+    const i64 groups = (a.I + NI - 1) / NI;
     i64 grid;
     if (a.T <= kLsThreads) {
         i64 R = kLsThreads / a.T;
@@ -204,20 +216,35 @@ LaunchResult launch_ls(hipStream_t s, const Args &a, double *partials, const cha
         geo.nchunks = (a.T + kLsThreads - 1) / kLsThreads;
         grid = a.O < 2048 ? a.O : 2048;
     }
-    hipLaunchKernelGGL((lockstep_kernel<Op>), dim3((unsigned)grid), dim3(kLsThreads), 0, s, a, geo, partials);
-    return LaunchResult{0, grid, name};
+    if (groups > 1) {
+        // at most 4096 partials in all; a multiple of 8 blocks per group keeps the groups of a step on one XCD
+        if (grid > 4096 / groups) grid = 4096 / groups;
+        if (grid >= 8) grid -= grid % 8;
+    }
+    const dim3 g((unsigned)grid, (unsigned)groups);
+    if constexpr (NI == 2 || NI == 4 || NI == 8) {
+        if (aligned && a.I % NI == 0) {
+            hipLaunchKernelGGL((lockstep_kernel<Op, true>), g, dim3(kLsThreads), 0, s, a, geo, partials);
+            return LaunchResult{0, grid * groups, name};
+        }
+    }
+    hipLaunchKernelGGL((lockstep_kernel<Op, false>), g, dim3(kLsThreads), 0, s, a, geo, partials);
+    return LaunchResult{0, grid * groups, name};
 }
 
 template <template <typename, typename, int> class OpT, class Args>
-LaunchResult dispatch_ls(hipStream_t s, int vdt, int cdt, const Args &a, double *partials, const char *name) {
+LaunchResult dispatch_ls(hipStream_t s, int vdt, int cdt, const Args &a, bool aligned, double *partials, const char *name) {
     // dtype pairs: (f32, f32), (f64, f64) and (f64 values, f32 coefficients: python-float gamma on fp64 data)
-    if (a.I < 2 || a.I > 8 || (vdt == 0 && cdt == 1) || a.T >= (1LL << 31) - 4096) return LaunchResult{2, 0, nullptr};
+    if (a.I < 2 || a.I > 31 || (vdt == 0 && cdt == 1) || a.T >= (1LL << 31) - 4096) return LaunchResult{2, 0, nullptr};
+    // groups of 8 or 4 when they divide I (full groups, vector loads), else balanced: 9 -> 5 + 4, 31 -> 8 + 8 + 8 + 7
+    const int groups = ((int)a.I + 7) / 8;
+    const int ni = a.I <= 8 ? (int)a.I : a.I % 8 == 0 ? 8 : a.I % 4 == 0 ? 4 : ((int)a.I + groups - 1) / groups;
 #define TRL_LS_CASE(N)                                                                                  \
     case N:                                                                                             \
-        if (vdt == 0) return launch_ls<OpT, float, float, N>(s, a, partials, name);                     \
-        if (cdt == 1) return launch_ls<OpT, double, double, N>(s, a, partials, name);                   \
-        return launch_ls<OpT, double, float, N>(s, a, partials, name);
-    switch ((int)a.I) {
+        if (vdt == 0) return launch_ls<OpT, float, float, N>(s, a, aligned, partials, name);                     \
+        if (cdt == 1) return launch_ls<OpT, double, double, N>(s, a, aligned, partials, name);                   \
+        return launch_ls<OpT, double, float, N>(s, a, aligned, partials, name);
+    switch (ni) {
         TRL_LS_CASE(2)
         TRL_LS_CASE(3)
         TRL_LS_CASE(4)
@@ -232,12 +259,20 @@ LaunchResult dispatch_ls(hipStream_t s, int vdt, int cdt, const Args &a, double 
 
 }  // namespace
 
+static bool al16(const void *p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; }
+
 LaunchResult launch_gae_lockstep(hipStream_t s, int vdt, int cdt, const GaeArgs &a) {
-    return dispatch_ls<GaeOp>(s, vdt, cdt, a, a.partials, "gae_scan_lockstep");
+    const bool al = al16(a.reward) && al16(a.value) && al16(a.next_value) && al16(a.done) && al16(a.terminated) &&
+                    al16(a.gamma_t) && al16(a.lg_t) && al16(a.advantage) && al16(a.value_target);
+    return dispatch_ls<GaeOp>(s, vdt, cdt, a, al, a.partials, "gae_scan_lockstep");
 }
 LaunchResult launch_td_lambda_lockstep(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a) {
-    return dispatch_ls<TdLambdaOp>(s, vdt, cdt, a, nullptr, "td_lambda_scan_lockstep");
+    const bool al = al16(a.reward) && al16(a.next_value) && al16(a.done) && al16(a.terminated) && al16(a.gamma_t) &&
+                    al16(a.lmbda_t) && al16(a.returns);
+    return dispatch_ls<TdLambdaOp>(s, vdt, cdt, a, al, nullptr, "td_lambda_scan_lockstep");
 }
 LaunchResult launch_vtrace_lockstep(hipStream_t s, int vdt, int cdt, const VtraceArgs &a) {
-    return dispatch_ls<VtraceOp>(s, vdt, cdt, a, nullptr, "vtrace_scan_lockstep");
+    const bool al = al16(a.log_pi) && al16(a.log_mu) && al16(a.value) && al16(a.next_value) && al16(a.reward) &&
+                    al16(a.done) && al16(a.terminated) && al16(a.gamma_t) && al16(a.advantage) && al16(a.vs);
+    return dispatch_ls<VtraceOp>(s, vdt, cdt, a, al, nullptr, "vtrace_scan_lockstep");
 }

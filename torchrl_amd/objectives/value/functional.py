@@ -222,10 +222,13 @@ def _shifted_pair(state_value: torch.Tensor, next_state_value: torch.Tensor, sha
     of the value network yields (reference: advantages.py:440-490).  The kernels then read that buffer in place
     (include/trl_value.h: ``next_state_value == NULL``), the value bytes once, instead of two copies of it."""
     sv, nsv = state_value, next_state_value
-    if grads or sv.dtype != vdt or nsv.dtype != vdt or sv.device != nsv.device:
-        return False
     nd = len(shape)
     td = time_dim if time_dim >= 0 else nd + time_dim
+    # cheapest test first (this runs on every call): the second window starts one time step behind the first
+    if grads or nsv.data_ptr() - sv.data_ptr() != sv.element_size() * sv.stride(td):
+        return False
+    if sv.dtype != vdt or nsv.dtype != vdt or sv.device != nsv.device:
+        return False
     if math.prod(shape[td + 1:]) != 1 or math.prod(shape) == 0 or sv.stride() != nsv.stride():
         return False
     if sv.untyped_storage().data_ptr() != nsv.untyped_storage().data_ptr() or nsv.storage_offset() != sv.storage_offset() + sv.stride(td):
@@ -405,18 +408,19 @@ def _lookback_workspace(lib, dev, O, T, I):
 
 
 def _wants_time_major(c, algo) -> bool:
-    """Few feature elements per step (I < 32) and outer rows too long for the LDS-transposing SCAN kernel
-    (T * I beyond one chunk): the SEQ family would walk every (o, i) row with I-strided, uncoalesced accesses
-    (measured [64 x 1000 x 5] fp32: 460 us).  Such calls are re-laid out time-major -- (O, T, I) -> (O * I, T)
-    with torch copies -- and take the I == 1 kernels (same call: 78 us, host-bound; [512 x 2000 x 3]: 1052 -> 78 us).  A kernel that carries the I
-    interleaved scans across time tiles itself is the planned replacement."""
+    """fp32 values with fp64 coefficients, few feature elements per step (I < 32) and outer rows too long for the
+    LDS-transposing SCAN kernel (T * I beyond one chunk): the lock-step kernels have no instantiation for that dtype
+    pair and the SEQ family would walk every (o, i) row with I-strided, uncoalesced accesses.  Such calls are
+    re-laid out time-major -- (O, T, I) -> (O * I, T) with torch copies -- and take the I == 1 kernels.  Every
+    other dtype pair runs on the lock-step kernels (I <= 31: [64 x 1000 x 16] fp32 20 us, 78 us on this route) or,
+    with many rows, on SEQ (capi.hip: lockstep_over_seq)."""
     chunk = 256 * (4 if c.vdt == torch.float32 else 2)
     if not (algo == ALGO_AUTO and 1 < c.I < 32 and c.T * c.I > chunk and c.O * c.T * c.I > 0):
         return False
+    if not (c.vdt == torch.float32 and c.cdt == torch.float64):
+        return False
     # measured: the re-layout costs ~25 us per million elements (seven transposing copies), SEQ ~32 us at I = 5
     # but ~13 us at I = 31 once there are enough (o, i) rows to hide its per-step latency (~0.46 us * T)
-    if c.I <= 8 and not (c.vdt == torch.float32 and c.cdt == torch.float64):
-        return False  # the lock-step kernels take it as it is
     return c.I <= 8 or c.O * c.I < 16384
 
 
