@@ -38,7 +38,7 @@ def algos(call):
     """SEQ always; SCAN when the family supports the shape (I == 1, or whole outer rows fit a chunk)."""
     chunk = 256 * (4 if call.vdt == torch.float32 else 2)
     out = [SEQ, SCAN] if (call.I == 1 or call.T * call.I <= chunk) else [SEQ]
-    if 2 <= call.I <= 31 and not (call.vdt == torch.float32 and call.cdt == torch.float64):
+    if 2 <= call.I <= 31:
         out.append(LOCKSTEP)  # a lane per time step, the I recurrences in lock step: any T
     return out
 
@@ -448,14 +448,19 @@ LONG_IL = [((16, 400, 5), -2), ((3, 2000, 3, 2), 1), ((64, 1000, 5, 1), -3), ((5
 
 @pytest.mark.parametrize("shape", [(16, 400, 5), (40, 700, 12)], ids=["16x400x5", "40x700x12"])
 def test_long_rows_few_features_fp32_values_fp64_gamma(shape):
-    """The one dtype pair the lock-step kernels do not instantiate: re-laid out time-major onto the I == 1 kernels."""
+    """fp32 values with an fp64 gamma tensor (arithmetic in fp64, outputs fp32) on the lock-step kernels."""
     r, v, nv, done, term, gam, lp, lm = _rand_inputs(shape, torch.float32, seed=32, p_term=0.01, p_trunc=0.01)
     gam = gam.double()
     oadv, ovt = O.gae(gam, 0.9, v, nv, r, done, term)
     adv, vt = F.generalized_advantage_estimate(cu(gam), 0.9, cu(v), cu(nv), cu(r), cu(done), cu(term))
-    assert F.last_kernel() in ("gae_scan_short", "gae_scan_long") and adv.is_contiguous()
+    assert F.last_kernel() == "gae_scan_lockstep" and adv.is_contiguous()
     torch.testing.assert_close(adv.cpu(), oadv, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(vt.cpu(), ovt, rtol=1e-5, atol=1e-5)
+    ova, ovs = O.vtrace(gam, lp, lm, v, nv, r, done, term)
+    va, vs = F.vtrace_advantage_estimate(cu(gam), cu(lp), cu(lm), cu(v), cu(nv), cu(r), cu(done), cu(term))
+    assert F.last_kernel() == "vtrace_scan_lockstep" and va.dtype == torch.float64
+    torch.testing.assert_close(va.cpu(), ova, rtol=1e-5, atol=1e-5)  # rho = exp(fp32): expf on the device, fp32 tolerance
+    torch.testing.assert_close(vs.cpu(), ovs, rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
@@ -493,7 +498,7 @@ def test_long_rows_with_few_features(shape, time_dim, dtype, bcast):
     assert F.last_kernel() == "gae_seq"
     check(adv_seq, oadv, True)
     # and the lock-step family on request, whatever AUTO picked (I <= 31: groups of <= 8 feature elements)
-    if gcall.I <= 31 and not (gcall.vdt == torch.float32 and gcall.cdt == torch.float64):
+    if gcall.I <= 31:
         adv_ls, vt_ls, st = F._launch_gae(gcall, want_stats=True, algo=LOCKSTEP)
         assert F.last_kernel() == "gae_scan_lockstep"
         check(adv_ls, oadv, False, done)

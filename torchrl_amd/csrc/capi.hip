@@ -80,7 +80,7 @@ static int check_shifted(const char *fn, const void *next_state_value, int64_t I
 // (R*T*I >= 95 % of 256*V elements: [8192x100x5] 23.0 vs 23.3 us, [8192x32x8] 11.4 vs 14.8), the lock-step
 // kernels otherwise ([8192x100x3] 15.5 vs 19.5, [8192x100x8] 38 vs 61).
 static bool prefer_lockstep(int val_dtype, int coef_dtype, int64_t T, int64_t I) {
-    if (I < 2 || I > 8 || (val_dtype == TRL_F32 && coef_dtype == TRL_F64)) return false;
+    if (I < 2 || I > 8) return false;
     const int64_t chunk = 256 * (val_dtype == TRL_F32 ? 4 : 2);
     if (T * I > chunk) return true;
     const int64_t R = chunk / (T * I);
@@ -156,7 +156,7 @@ int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward,
     if (res.status == TRL_ERR_UNSUPPORTED && ((algo == TRL_ALGO_AUTO && lockstep_over_seq(O, I)) || algo == TRL_ALGO_LOCKSTEP))
         res = launch_gae_lockstep(s, val_dtype, coef_dtype, a);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_LOCKSTEP)
-        return fail(TRL_ERR_UNSUPPORTED, "trl_gae_fwd: LOCKSTEP family needs 2 <= I <= 31 (and not fp32 values with fp64 coefficients)");
+        return fail(TRL_ERR_UNSUPPORTED, "trl_gae_fwd: LOCKSTEP family needs 2 <= I <= 31");
     if (res.status == TRL_ERR_UNSUPPORTED) res = launch_gae_seq(s, val_dtype, coef_dtype, a);
     if (res.status != 0) return fail(res.status, "trl_gae_fwd: launch rejected (grid too large?)");
     if (int rc = check_launch("trl_gae_fwd")) return rc;
@@ -196,7 +196,7 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype, const void *r
     if (res.status == TRL_ERR_UNSUPPORTED && rolling_gamma && ((algo == TRL_ALGO_AUTO && lockstep_over_seq(O, I)) || algo == TRL_ALGO_LOCKSTEP))
         res = launch_td_lambda_lockstep(s, val_dtype, coef_dtype, a);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_LOCKSTEP)
-        return fail(TRL_ERR_UNSUPPORTED, "trl_td_lambda_fwd: LOCKSTEP family needs 2 <= I <= 31 (not fp32 values with fp64 coefficients), rolling gamma");
+        return fail(TRL_ERR_UNSUPPORTED, "trl_td_lambda_fwd: LOCKSTEP family needs 2 <= I <= 31, rolling gamma");
     if (res.status == TRL_ERR_UNSUPPORTED) res = launch_td_lambda_seq(s, val_dtype, coef_dtype, a, rolling_gamma);
     if (res.status != 0) return fail(res.status, "trl_td_lambda_fwd: launch rejected (grid too large?)");
     if (int rc = check_launch("trl_td_lambda_fwd")) return rc;
@@ -230,7 +230,7 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_
     if (res.status == TRL_ERR_UNSUPPORTED && ((algo == TRL_ALGO_AUTO && lockstep_over_seq(O, I)) || algo == TRL_ALGO_LOCKSTEP))
         res = launch_vtrace_lockstep(s, val_dtype, coef_dtype, a);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_LOCKSTEP)
-        return fail(TRL_ERR_UNSUPPORTED, "trl_vtrace_fwd: LOCKSTEP family needs 2 <= I <= 31 (and not fp32 values with fp64 coefficients)");
+        return fail(TRL_ERR_UNSUPPORTED, "trl_vtrace_fwd: LOCKSTEP family needs 2 <= I <= 31");
     if (res.status == TRL_ERR_UNSUPPORTED) res = launch_vtrace_seq(s, val_dtype, coef_dtype, a);
     if (res.status != 0) return fail(res.status, "trl_vtrace_fwd: launch rejected (grid too large?)");
     if (int rc = check_launch("trl_vtrace_fwd")) return rc;

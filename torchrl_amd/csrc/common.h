@@ -128,7 +128,7 @@ LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a, 
 LaunchResult launch_td_lambda_scan(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, void *lb_ws, size_t lb_bytes);
 LaunchResult launch_vtrace_scan(hipStream_t s, int vdt, int cdt, const VtraceArgs &a, void *lb_ws, size_t lb_bytes);
 size_t scan_lookback_bytes(i64 O, i64 T, i64 I);
-// lock-step kernels: 2 <= I <= 31 (groups of <= 8 elements), not (fp32 values with fp64 coefficients), any T (status 2 otherwise); gae writes <= 4096 partials
+// lock-step kernels: 2 <= I <= 31 (groups of <= 8 elements), any T (status 2 otherwise); gae writes <= 4096 partials
 LaunchResult launch_gae_lockstep(hipStream_t s, int vdt, int cdt, const GaeArgs &a);
 LaunchResult launch_td_lambda_lockstep(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a);
 LaunchResult launch_vtrace_lockstep(hipStream_t s, int vdt, int cdt, const VtraceArgs &a);

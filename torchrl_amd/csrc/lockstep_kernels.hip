@@ -234,14 +234,14 @@ LaunchResult launch_ls(hipStream_t s, const Args &a, bool aligned, double *parti
 
 template <template <typename, typename, int> class OpT, class Args>
 LaunchResult dispatch_ls(hipStream_t s, int vdt, int cdt, const Args &a, bool aligned, double *partials, const char *name) {
-    // dtype pairs: (f32, f32), (f64, f64) and (f64 values, f32 coefficients: python-float gamma on fp64 data)
-    if (a.I < 2 || a.I > 31 || (vdt == 0 && cdt == 1) || a.T >= (1LL << 31) - 4096) return LaunchResult{2, 0, nullptr};
+    if (a.I < 2 || a.I > 31 || a.T >= (1LL << 31) - 4096) return LaunchResult{2, 0, nullptr};
     // groups of 8 or 4 when they divide I (full groups, vector loads), else balanced: 9 -> 5 + 4, 31 -> 8 + 8 + 8 + 7
     const int groups = ((int)a.I + 7) / 8;
     const int ni = a.I <= 8 ? (int)a.I : a.I % 8 == 0 ? 8 : a.I % 4 == 0 ? 4 : ((int)a.I + groups - 1) / groups;
 #define TRL_LS_CASE(N)                                                                                  \
     case N:                                                                                             \
-        if (vdt == 0) return launch_ls<OpT, float, float, N>(s, a, aligned, partials, name);                     \
+        if (vdt == 0 && cdt == 0) return launch_ls<OpT, float, float, N>(s, a, aligned, partials, name);    \
+        if (vdt == 0) return launch_ls<OpT, float, double, N>(s, a, aligned, partials, name);                     \
         if (cdt == 1) return launch_ls<OpT, double, double, N>(s, a, aligned, partials, name);                   \
         return launch_ls<OpT, double, float, N>(s, a, aligned, partials, name);
     switch (ni) {

@@ -26,7 +26,6 @@ have no counterpart here.
 from __future__ import annotations
 
 import contextlib
-import dataclasses
 import ctypes
 import struct
 import math
@@ -407,58 +406,10 @@ def _lookback_workspace(lib, dev, O, T, I):
     return _workspace(lib, dev, O, T, I)
 
 
-def _wants_time_major(c, algo) -> bool:
-    """fp32 values with fp64 coefficients, few feature elements per step (I < 32) and outer rows too long for the
-    LDS-transposing SCAN kernel (T * I beyond one chunk): the lock-step kernels have no instantiation for that dtype
-    pair and the SEQ family would walk every (o, i) row with I-strided, uncoalesced accesses.  Such calls are
-    re-laid out time-major -- (O, T, I) -> (O * I, T) with torch copies -- and take the I == 1 kernels.  Every
-    other dtype pair runs on the lock-step kernels (I <= 31: [64 x 1000 x 16] fp32 20 us, 78 us on this route) or,
-    with many rows, on SEQ (capi.hip: lockstep_over_seq)."""
-    chunk = 256 * (4 if c.vdt == torch.float32 else 2)
-    if not (algo == ALGO_AUTO and 1 < c.I < 32 and c.T * c.I > chunk and c.O * c.T * c.I > 0):
-        return False
-    if not (c.vdt == torch.float32 and c.cdt == torch.float64):
-        return False
-    # measured: the re-layout costs ~25 us per million elements (seven transposing copies), SEQ ~32 us at I = 5
-    # but ~13 us at I = 31 once there are enough (o, i) rows to hide its per-step latency (~0.46 us * T)
-    return c.I <= 8 or c.O * c.I < 16384
-
-
-def _time_major(c):
-    """The call with every tensor re-laid out as (O * I, T, 1), and the function that brings outputs back."""
-    O, T, I = c.O, c.T, c.I
-
-    def fwd(t):
-        if t is None:
-            return None
-        return t.view(O, T, I).transpose(1, 2).contiguous()
-
-    def mask(m):
-        if c.mask_bcast:
-            return m.view(O, 1, T).expand(O, I, T).contiguous()
-        return fwd(m)
-
-    kw = {f.name: getattr(c, f.name) for f in dataclasses.fields(c)}
-    for name, val in kw.items():
-        if isinstance(val, torch.Tensor):
-            kw[name] = mask(val) if name in ("done", "terminated") else fwd(val)
-    kw.update(shape=(O * I, T, 1), O=O * I, I=1, mask_bcast=0)
-    shape = c.shape
-
-    def back(t):
-        return t.view(O, I, T).transpose(1, 2).contiguous().view(shape)
-
-    return type(c)(**kw), back
-
-
 def _launch_gae(c: _GaeCall, want_stats: bool = False, algo: int = ALGO_AUTO, out=None):
     lib = _extension.get_lib()
     _require_hip(c.reward)
     dev = c.reward.device
-    if out is None and _wants_time_major(c, algo):
-        c2, back = _time_major(c)
-        adv, vt, stats = _launch_gae(c2, want_stats, algo)
-        return back(adv), back(vt), stats
     adv, vt = out if out is not None else (torch.empty(c.shape, dtype=c.vdt, device=dev), torch.empty(c.shape, dtype=c.vdt, device=dev))
     stats = ws = None
     ws_bytes = 0
@@ -489,10 +440,6 @@ def _launch_gae_normalize(c: _GaeCall, eps: float, algo: int = ALGO_AUTO, out=No
     lib = _extension.get_lib()
     _require_hip(c.reward)
     dev = c.reward.device
-    if out is None and _wants_time_major(c, algo):
-        c2, back = _time_major(c)
-        adv, vt, stats = _launch_gae_normalize(c2, eps, algo, None, want_stats, exchange)
-        return back(adv), back(vt), stats
     adv, vt = out if out is not None else (torch.empty(c.shape, dtype=c.vdt, device=dev), torch.empty(c.shape, dtype=c.vdt, device=dev))
     if c.O * c.T * c.I == 0:
         if exchange is not None:
@@ -1043,9 +990,6 @@ def _launch_td_lambda(c: _TdLambdaCall, out_dtype, algo: int = ALGO_AUTO) -> tor
     lib = _extension.get_lib()
     _require_hip(c.reward)
     dev = c.reward.device
-    if c.rolling and _wants_time_major(c, algo):
-        c2, back = _time_major(c)
-        return back(_launch_td_lambda(c2, out_dtype, algo))
     out = torch.empty(c.shape, dtype=c.vdt, device=dev)
     if c.O * c.T * c.I == 0:
         return out.to(out_dtype)
@@ -1250,10 +1194,6 @@ def _launch_vtrace(c: _VtraceCall, algo: int = ALGO_AUTO):
     lib = _extension.get_lib()
     _require_hip(c.reward)
     dev = c.reward.device
-    if _wants_time_major(c, algo):
-        c2, back = _time_major(c)
-        adv, vs = _launch_vtrace(c2, algo)
-        return back(adv), back(vs)
     odt = torch.promote_types(c.vdt, c.cdt)
     adv = torch.empty(c.shape, dtype=odt, device=dev)
     vs = torch.empty(c.shape, dtype=odt, device=dev)
