@@ -443,7 +443,7 @@ def test_broadcast_masks_read_in_place(shape, time_dim, dtype):
 
 LONG_IL = [((16, 400, 5), -2), ((3, 2000, 3, 2), 1), ((64, 1000, 5, 1), -3), ((5, 300, 4), -2), ((7, 257, 2), -2), ((2, 5000, 8), -2),
            ((300, 256, 7), -2), ((40, 700, 12), -2), ((6, 300, 9), -2), ((3, 130, 4, 4), 1), ((5, 260, 17), -2), ((2, 600, 31), -2),
-           ((70, 40, 31), -2)]
+           ((70, 40, 31), -2), ((1100, 300, 3), -2)]
 
 
 @pytest.mark.parametrize("shape", [(16, 400, 5), (40, 700, 12)], ids=["16x400x5", "40x700x12"])

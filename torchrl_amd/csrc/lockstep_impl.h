@@ -1,3 +1,5 @@
+// (shared by lockstep_gae.hip / lockstep_td_lambda.hip / lockstep_vtrace.hip: one translation unit per estimator, they
+// compile in parallel)
 // Lock-step scan kernels for a FEW feature elements per time step (2 <= I <= 31), any T.
 //
 // Element (o, t, i) sits at (o*T + t)*I + i: the I scans of an outer row are interleaved in memory (multi-agent
@@ -16,13 +18,15 @@
 // owns outer rows and walks each row's 256-step chunks from the end, the I carries (and V-trace's I next
 // state_values) in registers.  Same arithmetic contract as the SCAN family: every lane replays its step with the
 // reference's exact expression from its carry-in; row ends are hard resets, `done` a multiplication by zero.
+#include <stdlib.h>
+
+#pragma once
 #include "scan_core.h"
 
 namespace {
 
 using namespace scan;
 
-constexpr int kLsThreads = 256;
 
 struct LsGeom {
     i64 O, T;
@@ -31,18 +35,18 @@ struct LsGeom {
     i64 nchunks;         // short rows: chunks in total; long rows: chunks per row
 };
 
-template <class Op>
+template <class Op, int NW>
 struct LsShared {
-    typename Op::TC a[2][kWaves][Op::V], b[2][kWaves][Op::V];
-    int h[2][kWaves][Op::V];
-    typename Op::TS v0[2][kWaves][Op::V];
+    typename Op::TC a[2][NW][Op::V], b[2][NW][Op::V];
+    int h[2][NW][Op::V];
+    typename Op::TS v0[2][NW][Op::V];
 };
 
 // One chunk: lane = one time step (valid or not), op prepared with the step's I elements.
 // Xc / Xv (in/out, block-uniform): x / state_value of the step that follows the chunk, per feature element; on exit those
 // of the chunk's first step.
-template <class Op, class Emit>
-__device__ __forceinline__ void ls_chunk(const Op &op, LsShared<Op> &sh, int buf, bool valid, bool row_end,
+template <class Op, int NW, class Emit>
+__device__ __forceinline__ void ls_chunk(const Op &op, LsShared<Op, NW> &sh, int buf, bool valid, bool row_end,
                                          typename Op::TC (&Xc)[Op::V], typename Op::TS (&Xv)[Op::V], Emit &&emit) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
@@ -93,7 +97,7 @@ __device__ __forceinline__ void ls_chunk(const Op &op, LsShared<Op> &sh, int buf
         TC x = Xc[e], Cw = Xc[e];
         TS xv = Xv[e], Cv = Xv[e];
 #pragma unroll
-        for (int k = kWaves - 1; k >= 0; --k) {
+        for (int k = NW - 1; k >= 0; --k) {
             if (k == w) { Cw = x; Cv = xv; }
             x = apply(Aff<TC>{sh.a[buf][k][e], sh.b[buf][k][e], sh.h[buf][k][e]}, x);
             if (Op::kNeedsNext) xv = sh.v0[buf][k][e];
@@ -131,14 +135,15 @@ __device__ __forceinline__ void ls_load(const typename Op::Args &args, i64 step_
     });
 }
 
-template <class Op, bool VEC>
-__global__ __launch_bounds__(kLsThreads) void lockstep_kernel(typename Op::Args args, LsGeom geo, double *partials) {
+template <class Op, bool VEC, int NT>
+__global__ __launch_bounds__(NT) void lockstep_kernel(typename Op::Args args, LsGeom geo, double *partials) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
     typedef typename Op::TO TO;
     constexpr int NI = Op::V;
-    __shared__ LsShared<Op> sh;
-    __shared__ double red[2 * kLsThreads / kWave];
+    constexpr int NW = NT / kWave;
+    __shared__ LsShared<Op, NW> sh;
+    __shared__ double red[2 * NW];
     double s = 0.0, ss = 0.0;
     int buf = 0;
     const int I = geo.I, i0 = (int)blockIdx.y * NI;
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(kLsThreads) void lockstep_kernel(typename Op::Args 
         ls_load<Op, VEC>(args, step_index, I, i0, ne, valid, raw);
         Op op;
         op.prepare(args, raw);
-        ls_chunk<Op>(op, sh, buf, valid, row_end, Xc, Xv, [&](const TC(&xs)[NI], const TC(&x_in)[NI], const TS(&vn)[NI]) {
+        ls_chunk<Op, NW>(op, sh, buf, valid, row_end, Xc, Xv, [&](const TC(&xs)[NI], const TC(&x_in)[NI], const TS(&vn)[NI]) {
             TO o0[NI], o1[NI];
             op.outputs_ls(valid, xs, row_end, x_in, vn, o0, o1, s, ss);
             store_n<VEC>(Op::out_ptr(args, 0), step_index * I + i0, valid ? ne : 0, o0);
@@ -176,14 +181,14 @@ __global__ __launch_bounds__(kLsThreads) void lockstep_kernel(typename Op::Args 
 #pragma unroll
             for (int e = 0; e < NI; ++e) { Xc[e] = (TC)0; Xv[e] = (TS)0; }
             for (i64 c = geo.nchunks - 1; c >= 0; --c) {
-                const i64 t = c * kLsThreads + threadIdx.x;
+                const i64 t = c * NT + threadIdx.x;
                 const bool valid = t < geo.T;
                 run(row * geo.T + t, valid, valid && t == geo.T - 1, Xc, Xv);
             }
         }
     }
     if (partials) {
-        block_sum2<kLsThreads>(s, ss, red);
+        block_sum2<NT>(s, ss, red);
         if (threadIdx.x == 0) {
             const i64 b = (i64)blockIdx.y * gridDim.x + blockIdx.x;
             partials[2 * b] = s;
@@ -199,21 +204,22 @@ int ls_cus() {
     return n;
 }
 
-template <template <typename, typename, int> class OpT, typename TS, typename TG, int NI, class Args>
-LaunchResult launch_ls(hipStream_t s, const Args &a, bool aligned, double *partials, const char *name) {
+template <template <typename, typename, int> class OpT, typename TS, typename TG, int NI, int NT, class Args>
+LaunchResult launch_ls_nt(hipStream_t s, const Args &a, bool aligned, double *partials, const char *name) {
     typedef OpT<TS, TG, NI> Op;
     static const int cus = ls_cus();
     LsGeom geo{a.O, a.T, (int)a.I, 0, 0};
     const i64 groups = (a.I + NI - 1) / NI;
     i64 grid;
-    if (a.T <= kLsThreads) {
-        i64 R = kLsThreads / a.T;
+    if (a.T <= NT) {
+        i64 R = NT / a.T;
         if (R > a.O) R = a.O;
         geo.rows_per_chunk = (int)R;
         geo.nchunks = (a.O + R - 1) / R;
-        grid = geo.nchunks < (i64)cus * 8 ? geo.nchunks : (i64)cus * 8;
+        const i64 cap = (i64)cus * 8 * 256 / NT;
+        grid = geo.nchunks < cap ? geo.nchunks : cap;
     } else {
-        geo.nchunks = (a.T + kLsThreads - 1) / kLsThreads;
+        geo.nchunks = (a.T + NT - 1) / NT;
         grid = a.O < 2048 ? a.O : 2048;
     }
     if (groups > 1) {
@@ -224,12 +230,25 @@ LaunchResult launch_ls(hipStream_t s, const Args &a, bool aligned, double *parti
     const dim3 g((unsigned)grid, (unsigned)groups);
     if constexpr (NI == 2 || NI == 4 || NI == 8) {
         if (aligned && a.I % NI == 0) {
-            hipLaunchKernelGGL((lockstep_kernel<Op, true>), g, dim3(kLsThreads), 0, s, a, geo, partials);
+            hipLaunchKernelGGL((lockstep_kernel<Op, true, NT>), g, dim3(NT), 0, s, a, geo, partials);
             return LaunchResult{0, grid * groups, name};
         }
     }
-    hipLaunchKernelGGL((lockstep_kernel<Op, false>), g, dim3(kLsThreads), 0, s, a, geo, partials);
+    hipLaunchKernelGGL((lockstep_kernel<Op, false, NT>), g, dim3(NT), 0, s, a, geo, partials);
     return LaunchResult{0, grid * groups, name};
+}
+
+// Block size: 256 lanes.  512-lane blocks pack short rows better (T = 100: 98 % of the lanes hold a step instead of 78 %)
+// but measured slower on every shape tried ([4096x100x5] 30.4 vs 20.1 us, [8192x100x8] 55.2 vs 40.2, [8192x32x8] 16.7 vs
+// 12.5): half as many resident blocks to overlap one block's barrier phases with another's loads.
+template <template <typename, typename, int> class OpT, typename TS, typename TG, int NI, class Args>
+LaunchResult launch_ls(hipStream_t s, const Args &a, bool aligned, double *partials, const char *name) {
+    // 128-lane blocks when a long row's last chunk would leave a 256-lane block mostly idle and there are rows enough
+    // to keep the chip busy (T = 300: 3 chunks of 128 at 78 % instead of 2 of 256 at 59 %: [2048x300x5] 30.7 -> 20.3 us;
+    // short rows and few long rows are slower with 128: [8192x100x4] 24.0 vs 19.6, [64x1000x5] 22.9 vs 15.0)
+    auto fill = [&](i64 nt) { return (double)a.T / (double)(((a.T + nt - 1) / nt) * nt); };
+    if (a.T > 256 && a.O >= 1024 && fill(128) >= fill(256) + 0.1) return launch_ls_nt<OpT, TS, TG, NI, 128>(s, a, aligned, partials, name);
+    return launch_ls_nt<OpT, TS, TG, NI, 256>(s, a, aligned, partials, name);
 }
 
 template <template <typename, typename, int> class OpT, class Args>
@@ -257,22 +276,6 @@ LaunchResult dispatch_ls(hipStream_t s, int vdt, int cdt, const Args &a, bool al
     return LaunchResult{2, 0, nullptr};
 }
 
+inline bool al16(const void *p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; }
+
 }  // namespace
-
-static bool al16(const void *p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; }
-
-LaunchResult launch_gae_lockstep(hipStream_t s, int vdt, int cdt, const GaeArgs &a) {
-    const bool al = al16(a.reward) && al16(a.value) && al16(a.next_value) && al16(a.done) && al16(a.terminated) &&
-                    al16(a.gamma_t) && al16(a.lg_t) && al16(a.advantage) && al16(a.value_target);
-    return dispatch_ls<GaeOp>(s, vdt, cdt, a, al, a.partials, "gae_scan_lockstep");
-}
-LaunchResult launch_td_lambda_lockstep(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a) {
-    const bool al = al16(a.reward) && al16(a.next_value) && al16(a.done) && al16(a.terminated) && al16(a.gamma_t) &&
-                    al16(a.lmbda_t) && al16(a.returns);
-    return dispatch_ls<TdLambdaOp>(s, vdt, cdt, a, al, nullptr, "td_lambda_scan_lockstep");
-}
-LaunchResult launch_vtrace_lockstep(hipStream_t s, int vdt, int cdt, const VtraceArgs &a) {
-    const bool al = al16(a.log_pi) && al16(a.log_mu) && al16(a.value) && al16(a.next_value) && al16(a.reward) &&
-                    al16(a.done) && al16(a.terminated) && al16(a.gamma_t) && al16(a.advantage) && al16(a.vs);
-    return dispatch_ls<VtraceOp>(s, vdt, cdt, a, al, nullptr, "vtrace_scan_lockstep");
-}
