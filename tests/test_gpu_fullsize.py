@@ -122,3 +122,41 @@ def test_more_than_2_31_transitions(shape):
     assert abs(float(st[1]) - s) <= 1e-9 * n ** 0.5 * max(1.0, abs(s)) and abs(float(st[2]) - ss) <= 1e-10 * ss
     # the tail of the flat array was written (a 32-bit index would have wrapped long before)
     assert torch.isfinite(adv.flatten()[-(1 << 20):]).all() and bool((adv.flatten()[-(1 << 20):] != 0).any())
+
+
+@pytest.mark.parametrize("shape", [(140000, 32768), ((1 << 27) + 5, 33)], ids=["140000x32768_long_rows", "134M_rows_x33"])
+def test_shifted_layout_beyond_2_32_transitions(shape):
+    """The shifted value layout (one (O, T + 1) buffer read in place) with flat indices beyond 2^32: the row of an
+    element then comes from the floating-point division path (scan_core.h: row_of).  Rows from both ends and from
+    around the 2^32nd element against the CPU oracle; ~80 GB of HBM."""
+    from oracle import value_oracle as O
+
+    O_, T = shape
+    n = O_ * T
+    assert n > (1 << 32)
+    free, _ = torch.cuda.mem_get_info()
+    if free < n * 22:
+        pytest.skip("needs ~100 GB of free HBM")
+    g = torch.Generator(device=DEV).manual_seed(11)
+    buf = torch.randn(O_, T + 1, 1, generator=g, device=DEV)
+    r = torch.randn(O_, T, 1, generator=g, device=DEV)
+    done = torch.rand(O_, T, 1, generator=g, device=DEV) < 0.003
+    v, nv = buf[:, :-1], buf[:, 1:]
+    assert F._prepare_gae(0.99, 0.95, v, nv, r, done, None, -2).next_value is None
+    adv, vt = F.generalized_advantage_estimate(0.99, 0.95, v, nv, r, done)
+    mid = (1 << 32) // T
+    rows = sorted({0, 1, mid - 1, mid, mid + 1, O_ - 2, O_ - 1})
+    idx = torch.tensor(rows, device=DEV)
+    pick = lambda t: t.index_select(0, idx).cpu()
+    pb = pick(buf)
+    oadv, ovt = O.gae(0.99, 0.95, pb[:, :-1], pb[:, 1:], pick(r), pick(done), pick(done))
+    torch.testing.assert_close(pick(adv), oadv, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(pick(vt), ovt, rtol=1e-5, atol=1e-5)
+    d = pick(done)
+    assert torch.equal(pick(adv)[d], oadv[d])
+    tail = adv.flatten()[-(1 << 20):]
+    assert torch.isfinite(tail).all() and bool((tail != 0).any())
+    # value_target - advantage reproduces the first window of the buffer everywhere (exact up to one rounding)
+    for lo in range(0, O_, max(1, O_ // 8)):
+        hi = min(O_, lo + 4096)
+        torch.testing.assert_close(vt[lo:hi] - adv[lo:hi], v[lo:hi], rtol=0, atol=1e-5)

@@ -247,7 +247,7 @@ struct GaeOp {
                                             TO (&o1)[V], double &s, double &ss) const {
         finish(nvalid, x, o0, o1, s, ss);
     }
-    // lock-step layout (lockstep_kernels.hip): the lane's V elements are the V feature elements of ONE time step
+    // lock-step layout (lockstep_impl.h): the lane's V elements are the V feature elements of ONE time step
     __device__ __forceinline__ TS value(int e) const { return v[e]; }
     __device__ __forceinline__ void outputs_ls(bool valid, const TC (&x)[V], bool, const TC (&)[V], const TS (&)[V], TO (&o0)[V],
                                                TO (&o1)[V], double &s, double &ss) const {
