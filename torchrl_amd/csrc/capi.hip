@@ -76,13 +76,16 @@ static int check_shifted(const char *fn, const void *next_state_value, int64_t I
 }
 
 // I > 1 with whole outer rows inside one chunk: both the LDS-transposing SCAN kernel and the lock-step kernels
-// apply.  Measured (fp32 / fp64, T = 32..100, I = 2..8): the transposing kernel wins when its chunk is full
-// (R*T*I >= 95 % of 256*V elements: [8192x100x5] 23.0 vs 23.3 us, [8192x32x8] 11.4 vs 14.8), the lock-step
-// kernels otherwise ([8192x100x3] 15.5 vs 19.5, [8192x100x8] 38 vs 61).
+// apply.  Measured (transposing / lock-step us, fp32 unless noted): I = 2, 4, 8 read one vector per tensor and lane in
+// the lock-step kernels and win there -- [8192x64x4] 11.2 / 9.7, [8192x128x4] 28.9 / 19.0, [8192x128x8] 90.4 / 40.7,
+// [8192x128x2] 11.8 / 10.3, [8192x32x8] 11.8 / 11.4 (very short rows the other way: [16384x16x8] 10.0 / 10.9); every other
+// I, and fp64, goes by how full the transposing kernel's chunk is (R*T*I >= 95 % of 256*V elements: [8192x100x5] 23.1 /
+// 27.8, [8192x85x6] 23.7 / 29.1, [8192x32x8] fp64 22.0 / 35.8; below that [8192x100x3] 19.5 / 15.9).
 static bool prefer_lockstep(int val_dtype, int coef_dtype, int64_t T, int64_t I) {
     if (I < 2 || I > 8) return false;
     const int64_t chunk = 256 * (val_dtype == TRL_F32 ? 4 : 2);
     if (T * I > chunk) return true;
+    if (val_dtype == TRL_F32 && coef_dtype == TRL_F32 && (I == 2 || I == 4 || I == 8) && T * I >= 200) return true;
     const int64_t R = chunk / (T * I);
     return R * T * I * 100 < chunk * 95;
 }

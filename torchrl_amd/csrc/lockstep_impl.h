@@ -38,7 +38,7 @@ struct LsGeom {
 template <class Op, int NW>
 struct LsShared {
     typename Op::TC a[2][NW][Op::V], b[2][NW][Op::V];
-    int h[2][NW][Op::V];
+    int h[2][NW];
     typename Op::TS v0[2][NW][Op::V];
 };
 
@@ -54,43 +54,53 @@ __device__ __forceinline__ void ls_chunk(const Op &op, LsShared<Op, NW> &sh, int
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
     const int lir = lane & 15, row = lane >> 4;
 
-    Aff<TC> S[NI];
+    // The hard-reset flag of a map says "a row end lies in the range": it is a property of the LANES covered, the same
+    // for the I maps of a lane -- one register and one move per scan step instead of I.
+    TC Sa[NI], Sb[NI];
+    int Sh = (valid && row_end) ? 1 : 0;
 #pragma unroll
     for (int e = 0; e < NI; ++e) {
-        if (!valid) S[e] = Aff<TC>{(TC)1, (TC)0, 0};
-        else if (row_end) S[e] = Aff<TC>{(TC)0, op.step(e, op.init(e)), 1};
-        else { S[e].h = 0; op.affine(e, S[e].a, S[e].b); }
+        if (!valid) { Sa[e] = (TC)1; Sb[e] = (TC)0; }
+        else if (row_end) { Sa[e] = (TC)0; Sb[e] = op.step(e, op.init(e)); }
+        else op.affine(e, Sa[e], Sb[e]);
+    }
+    // S <- S o P (P = the map of the lanes that follow): a = S.a P.a, b = S.h ? S.b : S.b + S.a P.b, h = S.h | P.h
+#define TRL_LS_COMPOSE(COND, PA, PB, PH)                                  \
+    {                                                                     \
+        const int ph_ = (PH);                                             \
+        _Pragma("unroll") for (int e = 0; e < NI; ++e) {                  \
+            const TC pa_ = (PA), pb_ = (PB);                              \
+            if (COND) {                                                   \
+                const TC t_ = Sb[e] + Sa[e] * pb_;                        \
+                Sa[e] = Sa[e] * pa_;                                      \
+                Sb[e] = Sh ? Sb[e] : t_;                                  \
+            }                                                             \
+        }                                                                 \
+        if (COND) Sh |= ph_;                                              \
     }
     // inclusive suffix scan over the wave, I maps per move
-#define TRL_LS_STEP(OFF)                                                                                     \
-    _Pragma("unroll") for (int e = 0; e < NI; ++e) {                                                         \
-        Aff<TC> p{dpp_mov<0x100 + OFF>(S[e].a), dpp_mov<0x100 + OFF>(S[e].b), dpp_mov<0x100 + OFF>(S[e].h)}; \
-        if (lir + OFF < 16) S[e] = compose(S[e], p);                                                         \
-    }
-    TRL_LS_STEP(1)
-    TRL_LS_STEP(2)
-    TRL_LS_STEP(4)
-    TRL_LS_STEP(8)
-#undef TRL_LS_STEP
-#pragma unroll
-    for (int e = 0; e < NI; ++e) {
-        Aff<TC> p{__shfl(S[e].a, (row + 1) << 4, kWave), __shfl(S[e].b, (row + 1) << 4, kWave), __shfl(S[e].h, (row + 1) << 4, kWave)};
-        if ((row & 1) == 0) S[e] = compose(S[e], p);
-        p = Aff<TC>{__shfl(S[e].a, 32, kWave), __shfl(S[e].b, 32, kWave), __shfl(S[e].h, 32, kWave)};
-        if (row < 2) S[e] = compose(S[e], p);
-    }
+    TRL_LS_COMPOSE(lir + 1 < 16, dpp_mov<0x101>(Sa[e]), dpp_mov<0x101>(Sb[e]), dpp_mov<0x101>(Sh))
+    TRL_LS_COMPOSE(lir + 2 < 16, dpp_mov<0x102>(Sa[e]), dpp_mov<0x102>(Sb[e]), dpp_mov<0x102>(Sh))
+    TRL_LS_COMPOSE(lir + 4 < 16, dpp_mov<0x104>(Sa[e]), dpp_mov<0x104>(Sb[e]), dpp_mov<0x104>(Sh))
+    TRL_LS_COMPOSE(lir + 8 < 16, dpp_mov<0x108>(Sa[e]), dpp_mov<0x108>(Sb[e]), dpp_mov<0x108>(Sh))
+    TRL_LS_COMPOSE((row & 1) == 0, __shfl(Sa[e], (row + 1) << 4, kWave), __shfl(Sb[e], (row + 1) << 4, kWave), __shfl(Sh, (row + 1) << 4, kWave))
+    TRL_LS_COMPOSE(row < 2, __shfl(Sa[e], 32, kWave), __shfl(Sb[e], 32, kWave), __shfl(Sh, 32, kWave))
+#undef TRL_LS_COMPOSE
     if (lane == 0) {
+        sh.h[buf][w] = Sh;
 #pragma unroll
         for (int e = 0; e < NI; ++e) {
-            sh.a[buf][w][e] = S[e].a;
-            sh.b[buf][w][e] = S[e].b;
-            sh.h[buf][w][e] = S[e].h;
+            sh.a[buf][w][e] = Sa[e];
+            sh.b[buf][w][e] = Sb[e];
             if (Op::kNeedsNext) sh.v0[buf][w][e] = op.value(e);
         }
     }
     __syncthreads();
     TC xs[NI], x_in[NI];
     TS vn[NI];
+    // exclusive map (everything after this lane inside the wave) = the inclusive one of the next lane
+    int Eh = dpp_mov<0x130>(Sh);
+    if (lane == kWave - 1) Eh = 0;
 #pragma unroll
     for (int e = 0; e < NI; ++e) {
         // carry into this wave from the waves that follow it and from the chunk's carry-in
@@ -99,13 +109,12 @@ __device__ __forceinline__ void ls_chunk(const Op &op, LsShared<Op, NW> &sh, int
 #pragma unroll
         for (int k = NW - 1; k >= 0; --k) {
             if (k == w) { Cw = x; Cv = xv; }
-            x = apply(Aff<TC>{sh.a[buf][k][e], sh.b[buf][k][e], sh.h[buf][k][e]}, x);
+            x = apply(Aff<TC>{sh.a[buf][k][e], sh.b[buf][k][e], sh.h[buf][k]}, x);
             if (Op::kNeedsNext) xv = sh.v0[buf][k][e];
         }
         Xc[e] = x;
         Xv[e] = xv;
-        // exclusive map (everything after this lane inside the wave) = the inclusive one of the next lane
-        Aff<TC> E{dpp_mov<0x130>(S[e].a), dpp_mov<0x130>(S[e].b), dpp_mov<0x130>(S[e].h)};
+        Aff<TC> E{dpp_mov<0x130>(Sa[e]), dpp_mov<0x130>(Sb[e]), Eh};
         if (lane == kWave - 1) E = Aff<TC>{(TC)1, (TC)0, 0};
         vn[e] = Op::kNeedsNext ? dpp_mov<0x130>(op.value(e)) : (TS)0;
         if (Op::kNeedsNext && lane == kWave - 1) vn[e] = Cv;
@@ -135,8 +144,18 @@ __device__ __forceinline__ void ls_load(const typename Op::Args &args, i64 step_
     });
 }
 
+// Occupancy target (waves per SIMD) for the fp32 GAE / TD(lambda) kernels: without it the register allocator lands a few
+// registers above a threshold for some I (I = 3: 98 VGPRs = 4 waves where 96 give 5; [8192x100x3] 16.6 vs 14.9 us).
+// V-trace and the fp64 kernels need more registers than any useful target leaves them (they spill): no target there.
+template <class Op>
+constexpr int ls_waves() {
+    if (Op::kNeedsNext) return 1;
+    if (sizeof(typename Op::TC) != 4) return Op::V <= 2 ? 4 : Op::V <= 5 ? 3 : 2;
+    return Op::V <= 3 ? 5 : Op::V <= 5 ? 4 : 3;
+}
+
 template <class Op, bool VEC, int NT>
-__global__ __launch_bounds__(NT) void lockstep_kernel(typename Op::Args args, LsGeom geo, double *partials) {
+__global__ __launch_bounds__(NT, ls_waves<Op>()) void lockstep_kernel(typename Op::Args args, LsGeom geo, double *partials) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
     typedef typename Op::TO TO;
