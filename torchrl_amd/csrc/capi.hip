@@ -77,7 +77,7 @@ static int check_shifted(const char *fn, const void *next_state_value, int64_t I
 
 // I > 1 with whole outer rows inside one chunk: both the LDS-transposing SCAN kernel and the lock-step kernels
 // apply.  Measured (transposing / lock-step us, fp32 unless noted): I = 2, 4, 8 read one vector per tensor and lane in
-// the lock-step kernels and win there -- [8192x64x4] 11.2 / 9.7, [8192x128x4] 28.9 / 19.0, [8192x128x8] 90.4 / 40.7,
+// the lock-step kernels and win there -- [8192x64x4] 11.2 / 9.7, [8192x128x4] 28.9 / 19.0, [8192x128x8] 39.9 / 40.7,
 // [8192x128x2] 11.8 / 10.3, [8192x32x8] 11.8 / 11.4 (very short rows the other way: [16384x16x8] 10.0 / 10.9); every other
 // I, and fp64, goes by how full the transposing kernel's chunk is (R*T*I >= 95 % of 256*V elements: [8192x100x5] 23.1 /
 // 27.8, [8192x85x6] 23.7 / 29.1, [8192x32x8] fp64 22.0 / 35.8; below that [8192x100x3] 19.5 / 15.9).

@@ -124,15 +124,22 @@ __global__ __launch_bounds__(kShortThreads) void scan_short_kernel(typename Op::
 #ifndef IL_WAVES
 #define IL_WAVES 4
 #endif
-template <class Op, bool VEC, bool WAVE_INDEP>
+template <class Op, bool VEC, bool WAVE_INDEP, bool PAD>
 __global__ __launch_bounds__(kTeam, IL_WAVES) void scan_interleaved_kernel(typename Op::Args args, ScanGeom geo, int I, double *partials) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
     typedef typename Op::TO TO;
     constexpr int V = Op::V;
     constexpr int CH = kTeam * V;
-    __shared__ __align__(16) unsigned char lds_in[sizeof(typename Op::Raw) * kTeam];
-    __shared__ __align__(16) TO lds_out[Op::kNumOut][CH];
+    // The gather / scatter by (o, i) row walks the LDS arrays with a stride of V*I elements between lanes.  When that is a
+    // multiple of 16 words (fp32 I = 4, 8, 16, 24) every lane of a row hits one or two of the 32 banks ([8192x128x8] 90 us): the arrays then carry
+    // one pad element per 32 (index p -> p + p / 32; 40 us).  Other I keep the plain layout: padding costs the staging its
+    // 16-byte LDS accesses ([4096x100x5] 12.6 -> 14.2 us with it).
+    constexpr int CHP = CH + CH / 32;
+    constexpr bool padded = PAD;  // chosen by the launcher (launch_scan)
+    auto pad = [&](int p) { return padded ? p + (p >> 5) : p; };
+    __shared__ __align__(16) unsigned char lds_in[sizeof(typename Op::Raw) * kTeam / 32 * 33];
+    __shared__ __align__(16) TO lds_out[Op::kNumOut][CHP];
     __shared__ TeamShared<Op> sh;
     __shared__ double red[2 * kWaves];
     const int lane_off = (int)threadIdx.x * V;
@@ -147,8 +154,8 @@ __global__ __launch_bounds__(kTeam, IL_WAVES) void scan_interleaved_kernel(typen
         unsigned ol = rv / (unsigned)I, i = rv % (unsigned)I;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            pe[e] = (int)((ol * T + t) * (unsigned)I + i);
-            pm[e] = (int)(ol * T + t);
+            pe[e] = pad((int)((ol * T + t) * (unsigned)I + i));
+            pm[e] = pad((int)(ol * T + t));
             if (++t == T) { t = 0; if (++i == (unsigned)I) { i = 0; ++ol; } }
         }
     }
@@ -194,11 +201,17 @@ __global__ __launch_bounds__(kTeam, IL_WAVES) void scan_interleaved_kernel(typen
             Op::for_each_input(args, cur, [&](auto *base, auto &arr) {
                 typedef typename std::remove_reference<decltype(arr[0])>::type E;
                 if (base) {
-                    E *dst = (E *)(lds_in + off) + lane_off;
+                    if (padded) {  // a lane's V elements share a group of 32: contiguous, but no longer 16-byte aligned
+                        E *dst = (E *)(lds_in + off) + pad(lane_off);
 #pragma unroll
-                    for (int e = 0; e < V; ++e) dst[e] = arr[e];
+                        for (int e = 0; e < V; ++e) dst[e] = arr[e];
+                    } else {
+                        E *dst = (E *)(lds_in + off) + lane_off;
+#pragma unroll
+                        for (int e = 0; e < V; ++e) dst[e] = arr[e];
+                    }
                 }
-                off += sizeof(E) * CH;
+                off += sizeof(E) * CHP;
             });
         }
         __syncthreads();
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(kTeam, IL_WAVES) void scan_interleaved_kernel(typen
 #pragma unroll
                     for (int e = 0; e < V; ++e) arr[e] = e < nvalid ? src[(sizeof(E) == 1 && bcast) ? pm[e] : pe[e]] : (E)0;
                 }
-                off += sizeof(E) * CH;
+                off += sizeof(E) * CHP;
             });
         }
         Op op;
@@ -234,10 +247,18 @@ __global__ __launch_bounds__(kTeam, IL_WAVES) void scan_interleaved_kernel(typen
         __syncthreads();
         {
             TO o0[V], o1[V];
+            if (padded) {
 #pragma unroll
-            for (int e = 0; e < V; ++e) {
-                o0[e] = lds_out[0][lane_off + e];
-                o1[e] = lds_out[Op::kNumOut - 1][lane_off + e];
+                for (int e = 0; e < V; ++e) {
+                    o0[e] = lds_out[0][pad(lane_off) + e];
+                    o1[e] = lds_out[Op::kNumOut - 1][pad(lane_off) + e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    o0[e] = lds_out[0][lane_off + e];
+                    o1[e] = lds_out[Op::kNumOut - 1][lane_off + e];
+                }
             }
             store_outputs<Op, VEC>(args, start + lane_off, nvalid, o0, o1);
         }
@@ -587,7 +608,15 @@ LaunchResult launch_scan(hipStream_t s, const typename Op::Args &a, const Plan &
     }
     if (p.interleaved) {
       if constexpr (!Op::kShifted) {
-#define TRL_LAUNCH(VEC, WI) hipLaunchKernelGGL((scan_interleaved_kernel<Op, VEC, WI>), grid, dim3(kTeam), 0, s, a, geo, (int)I, partials)
+        // bank-conflict padding of the LDS arrays: pays when a row spans 16 lanes or more ([8192x32x8] fp32, 8 lanes per
+        // row: 11.8 us plain, 12.9 padded; [8192x128x8] 90 -> 40, [8192x64x16] 55 -> 39, [8192x32x8] fp64 22.0 -> 20.3)
+        const i64 stride_words = (i64)Op::V * I * (i64)(sizeof(typename Op::TS) / 4);  // between the lanes of one (o, i) row
+        const bool pad_lds = stride_words % 16 == 0 && T / Op::V >= 16;                 // a row folds onto <= 2 of the 32 banks
+#define TRL_LAUNCH(VEC, WI)                                                                                                   \
+    do {                                                                                                                      \
+        if (pad_lds) hipLaunchKernelGGL((scan_interleaved_kernel<Op, VEC, WI, true>), grid, dim3(kTeam), 0, s, a, geo, (int)I, partials); \
+        else hipLaunchKernelGGL((scan_interleaved_kernel<Op, VEC, WI, false>), grid, dim3(kTeam), 0, s, a, geo, (int)I, partials);          \
+    } while (0)
         if (p.wave_indep) { if (p.vec) TRL_LAUNCH(true, true); else TRL_LAUNCH(false, true); }
         else              { if (p.vec) TRL_LAUNCH(true, false); else TRL_LAUNCH(false, false); }
 #undef TRL_LAUNCH
