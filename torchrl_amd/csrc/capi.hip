@@ -76,16 +76,16 @@ static int check_shifted(const char *fn, const void *next_state_value, int64_t I
 }
 
 // I > 1 with whole outer rows inside one chunk: both the LDS-transposing SCAN kernel and the lock-step kernels
-// apply.  Measured (transposing / lock-step us, fp32 unless noted): I = 2, 4, 8 read one vector per tensor and lane in
-// the lock-step kernels and win there -- [8192x64x4] 11.2 / 9.7, [8192x128x4] 28.9 / 19.0, [8192x128x8] 39.9 / 40.7,
-// [8192x128x2] 11.8 / 10.3, [8192x32x8] 11.8 / 11.4 (very short rows the other way: [16384x16x8] 10.0 / 10.9); every other
-// I, and fp64, goes by how full the transposing kernel's chunk is (R*T*I >= 95 % of 256*V elements: [8192x100x5] 23.1 /
-// 27.8, [8192x85x6] 23.7 / 29.1, [8192x32x8] fp64 22.0 / 35.8; below that [8192x100x3] 19.5 / 15.9).
+// apply.  Measured (transposing / lock-step us, fp32 unless noted): the transposing kernel when its chunk is full
+// (R*T*I >= 95 % of 256*V elements) -- [8192x100x5] 23.1 / 27.8, [8192x85x6] 23.7 / 29.1, [8192x128x8] 36.0 / 39.4,
+// [8192x32x8] 10.8 / 12.3, [8192x128x2] 10.6 / 10.8, [8192x32x8] fp64 20.3 / 35.8 -- except I = 4, where a lane of the
+// lock-step kernels reads exactly one 16-byte vector per tensor: [8192x64x4] 10.2 / 9.8, [8192x128x4] 20.3 / 18.3,
+// [8192x200x4] 35.7 / 33.6; below 95 % the lock-step kernels ([8192x100x3] 19.5 / 15.9).
 static bool prefer_lockstep(int val_dtype, int coef_dtype, int64_t T, int64_t I) {
     if (I < 2 || I > 8) return false;
     const int64_t chunk = 256 * (val_dtype == TRL_F32 ? 4 : 2);
     if (T * I > chunk) return true;
-    if (val_dtype == TRL_F32 && coef_dtype == TRL_F32 && (I == 2 || I == 4 || I == 8) && T * I >= 200) return true;
+    if (val_dtype == TRL_F32 && coef_dtype == TRL_F32 && I == 4) return true;
     const int64_t R = chunk / (T * I);
     return R * T * I * 100 < chunk * 95;
 }

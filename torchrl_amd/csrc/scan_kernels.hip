@@ -132,12 +132,12 @@ __global__ __launch_bounds__(kTeam, IL_WAVES) void scan_interleaved_kernel(typen
     constexpr int V = Op::V;
     constexpr int CH = kTeam * V;
     // The gather / scatter by (o, i) row walks the LDS arrays with a stride of V*I elements between lanes.  When that is a
-    // multiple of 16 words (fp32 I = 4, 8, 16, 24) every lane of a row hits one or two of the 32 banks ([8192x128x8] 90 us): the arrays then carry
-    // one pad element per 32 (index p -> p + p / 32; 40 us).  Other I keep the plain layout: padding costs the staging its
-    // 16-byte LDS accesses ([4096x100x5] 12.6 -> 14.2 us with it).
+    // multiple of 8 words a row's lanes fold onto 4, 2 or 1 of the 32 banks ([8192x128x8] 90 us): the arrays then carry 4
+    // pad elements per 128 (index p -> p + 4 * (p / 128)), which spreads the lanes again and keeps the staging's 16-byte
+    // LDS accesses aligned (34 us; one pad element per 32 was conflict-free but made the staging scalar: 40 us).
     constexpr int CHP = CH + CH / 32;
     constexpr bool padded = PAD;  // chosen by the launcher (launch_scan)
-    auto pad = [&](int p) { return padded ? p + (p >> 5) : p; };
+    auto pad = [&](int p) { return padded ? p + ((p >> 7) << 2) : p; };
     __shared__ __align__(16) unsigned char lds_in[sizeof(typename Op::Raw) * kTeam / 32 * 33];
     __shared__ __align__(16) TO lds_out[Op::kNumOut][CHP];
     __shared__ TeamShared<Op> sh;
@@ -201,8 +201,8 @@ __global__ __launch_bounds__(kTeam, IL_WAVES) void scan_interleaved_kernel(typen
             Op::for_each_input(args, cur, [&](auto *base, auto &arr) {
                 typedef typename std::remove_reference<decltype(arr[0])>::type E;
                 if (base) {
-                    if (padded) {  // a lane's V elements share a group of 32: contiguous, but no longer 16-byte aligned
-                        E *dst = (E *)(lds_in + off) + pad(lane_off);
+                    if (padded) {  // a lane's V elements share a group: contiguous and still aligned
+                        E *dst = (E *)__builtin_assume_aligned((E *)(lds_in + off) + pad(lane_off), V * sizeof(E) <= 16 ? V * sizeof(E) : 16);
 #pragma unroll
                         for (int e = 0; e < V; ++e) dst[e] = arr[e];
                     } else {
@@ -608,10 +608,10 @@ LaunchResult launch_scan(hipStream_t s, const typename Op::Args &a, const Plan &
     }
     if (p.interleaved) {
       if constexpr (!Op::kShifted) {
-        // bank-conflict padding of the LDS arrays: pays when a row spans 16 lanes or more ([8192x32x8] fp32, 8 lanes per
-        // row: 11.8 us plain, 12.9 padded; [8192x128x8] 90 -> 40, [8192x64x16] 55 -> 39, [8192x32x8] fp64 22.0 -> 20.3)
+        // bank-conflict padding of the LDS arrays ([8192x128x8] 90 -> 34 us, [8192x64x16] 55 -> 34, [8192x32x8] 11.5 -> 10.1,
+        // [8192x100x10] 41.3 -> 40.1; no effect for odd strides: [4096x100x5] 13.0 / 13.1)
         const i64 stride_words = (i64)Op::V * I * (i64)(sizeof(typename Op::TS) / 4);  // between the lanes of one (o, i) row
-        const bool pad_lds = stride_words % 16 == 0 && T / Op::V >= 16;                 // a row folds onto <= 2 of the 32 banks
+        const bool pad_lds = stride_words % 8 == 0;                                     // a row folds onto <= 4 of the 32 banks
 #define TRL_LAUNCH(VEC, WI)                                                                                                   \
     do {                                                                                                                      \
         if (pad_lds) hipLaunchKernelGGL((scan_interleaved_kernel<Op, VEC, WI, true>), grid, dim3(kTeam), 0, s, a, geo, (int)I, partials); \
