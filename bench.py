@@ -33,9 +33,9 @@ GAMMA, LMBDA, EPS = 0.99, 0.95, 1e-4
 BYTES_PER_TRANSITION = 22  # fp32 GAE: 3x4 B + 2x1 B read, 2x4 B written; normalise adds no compulsory traffic
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 # HBM bytes per launch of the fused kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-# passes, FETCH_SIZE x2 as the guide prescribes for gfx950): profiles/r01_g_bench_pmc_hbm_traffic.json.  A counter
+# passes, FETCH_SIZE x2 as the guide prescribes for gfx950): profiles/r01_h_bench_pmc_hbm_traffic.json.  A counter
 # pass cannot run inside the timed bench, so the measured figure is carried here; null for the unprofiled N > 1 path.
-PMC_TRAFFIC_BYTES_FUSED = 46797703
+PMC_TRAFFIC_BYTES_FUSED = 46802129
 
 
 def make_inputs(dev, seed):
