@@ -237,3 +237,21 @@ def test_vtrace_gradient_to_gamma(dtype, form):
     for name, a, b in zip(("gamma", "v", "nv", "r"), got, want):
         assert a.shape == b.shape and a.dtype == dtype
         torch.testing.assert_close(a.double(), b, msg=lambda m, n=name: f"{n}: {m}", **tol)
+
+
+def test_vtrace_gradient_to_broadcast_log_probs():
+    """A joint log-prob of shape [B, T, 1] with per-agent values [B, T, 3]: its gradient is summed over the agents."""
+    shape = (5, 20, 3)
+    v, nv, r, done, term, _, wa, wv = _inputs(shape, torch.float64)
+    g = torch.Generator().manual_seed(6)
+    lp = (0.5 * torch.randn(5, 20, 1, generator=g, dtype=torch.float64)).to(DEV).requires_grad_(True)
+    lm = (0.5 * torch.randn(5, 20, 1, generator=g, dtype=torch.float64)).to(DEV).requires_grad_(True)
+    adv, vs = F.vtrace_advantage_estimate(0.97, lp, lm, v, nv, r, done, term)
+    got = torch.autograd.grad((adv * wa).sum() + (vs * wv).sum(), (lp, lm, v))
+    d = lambda x: x.detach().clone().requires_grad_(True)
+    lp2, lm2, v2 = d(lp), d(lm), d(v)
+    a2, s2 = torch_vtrace(float(torch.tensor(0.97)), lp2.expand(shape), lm2.expand(shape), v2, nv.detach(), r.detach(), done, term, 1.0, 1.0)
+    want = torch.autograd.grad((a2 * wa).sum() + (s2 * wv).sum(), (lp2, lm2, v2))
+    for a, b in zip(got, want):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=1e-9, atol=1e-9)

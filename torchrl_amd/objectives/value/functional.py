@@ -661,18 +661,7 @@ class _VtraceFunction(torch.autograd.Function):
         d_nv = X * rb * g_nt
         d_nv = torch.cat([d_nv[:, :-1], d_nv[:, -1:] + d_vsp[:, -1:]], 1)
         outs = (d_lp, -d_lp, s_tot - w, d_nv, w)
-        def back(o, d, sh):
-            o = o.reshape(c.shape)
-            if tuple(sh) != tuple(c.shape):  # a broadcast log-prob: sum the gradient over the expanded dims
-                while len(sh) < o.dim():
-                    sh = tuple(sh) + (1,)
-                o = o.sum_to_size(sh).reshape(ctx.ins[0][1] if False else sh)
-            return o.to(d)
-
-        res = []
-        for o, (d, sh) in zip(outs, ctx.ins):
-            g = back(o, d, tuple(sh))
-            res.append(g.reshape(sh) if g.numel() == math.prod(sh) else g)
+        res = [o.reshape(c.shape).to(d) for o, (d, _) in zip(outs, ctx.ins)]
         d_gamma = None
         if ctx.gamma_e is not None:  # gamma enters as gamma * not_terminated (delta, advantage) and gamma * not_done (trace)
             d_gamma = _coef_grad(nt * rb * (A * vsp + X * nv) + nd * X * x_next * cb, ctx.gamma_e, c)
@@ -1230,7 +1219,9 @@ def vtrace_advantage_estimate(
     call = _prepare_vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward, done, terminated,
                            rho_thresh, c_thresh, time_dim)
     if _needs_grad(log_pi, log_mu, state_value, next_state_value, reward, gamma):
-        return _VtraceFunction.apply(log_pi, log_mu, state_value, next_state_value, reward,
+        # broadcast log-probabilities enter as differentiable full-shape views: autograd sums their gradient back
+        full = lambda t: t if tuple(t.shape) == call.shape else _expand_coef(t, call.shape, time_dim)
+        return _VtraceFunction.apply(full(log_pi), full(log_mu), state_value, next_state_value, reward,
                                      _coef_leaf(gamma, call.shape, time_dim), call)
     return _launch_vtrace(call)
 
