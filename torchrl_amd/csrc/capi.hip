@@ -105,6 +105,59 @@ int trl_internal_fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// trl_gae_fwd with the reduction of the per-block moments optional: `want_partials` makes the kernels write them to the
+// workspace, `stats` (may be NULL even then) receives their sum from one more single-block launch; *npartials_out tells
+// the caller how many there are (trl_gae_normalize_fwd lets the scale pass reduce them itself: one launch fewer).
+static int gae_fwd_impl(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
+                        const void *next_state_value, const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                        const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
+                        int64_t O, int64_t T, int64_t I, void *advantage, void *value_target,
+                        double *stats, void *workspace, size_t workspace_bytes, int algo, bool want_partials,
+                        i64 *npartials_out) {
+    if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: bad dtype");
+    if (int rc = check_dims("trl_gae_fwd", O, T, I)) return rc;
+    if (!reward || !state_value || !done || !terminated || !advantage || !value_target)
+        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: null tensor pointer");
+    if (int rc = check_shifted("trl_gae_fwd", next_state_value, I, algo)) return rc;
+    if (lg_t && !gamma_t) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: lg_t given without gamma_t");
+    if (want_partials) {
+        if (!workspace || workspace_bytes < trl_workspace_bytes(O, T, I))
+            return fail(TRL_ERR_WORKSPACE, "trl_gae_fwd: stats requested but workspace is %zu bytes, need %zu",
+                        workspace_bytes, trl_workspace_bytes(O, T, I));
+        if (((uintptr_t)workspace & 7) != 0) return fail(TRL_ERR_WORKSPACE, "trl_gae_fwd: workspace must be 8-byte aligned");
+    }
+    GaeArgs a{reward, state_value, next_state_value, done, terminated, gamma_t, lg_t, gamma, lmbda, lg,
+              O, T, I, advantage, value_target, want_partials ? (double *)((char *)workspace + kWsPartialsOffset) : nullptr,
+              (mask_bcast && I > 1) ? 1 : 0};
+    hipStream_t s = (hipStream_t)stream;
+    if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ && algo != TRL_ALGO_LOCKSTEP)
+        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: unknown algo %d", algo);
+    LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
+    size_t lb_bytes = 0;
+    void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
+    if (algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I)) res = launch_gae_lockstep(s, val_dtype, coef_dtype, a);
+    if (res.status == TRL_ERR_UNSUPPORTED && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN))
+        res = launch_gae_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
+    if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
+        return fail(TRL_ERR_UNSUPPORTED, "trl_gae_fwd: SCAN family does not support this shape (needs I == 1)");
+    if (res.status == TRL_ERR_UNSUPPORTED && ((algo == TRL_ALGO_AUTO && lockstep_over_seq(O, I)) || algo == TRL_ALGO_LOCKSTEP))
+        res = launch_gae_lockstep(s, val_dtype, coef_dtype, a);
+    if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_LOCKSTEP)
+        return fail(TRL_ERR_UNSUPPORTED, "trl_gae_fwd: LOCKSTEP family needs 2 <= I <= 31");
+    if (res.status == TRL_ERR_UNSUPPORTED) res = launch_gae_seq(s, val_dtype, coef_dtype, a);
+    if (res.status != 0) return fail(res.status, "trl_gae_fwd: launch rejected (grid too large?)");
+    if (int rc = check_launch("trl_gae_fwd")) return rc;
+    if (stats) {
+        launch_reduce_partials(s, (const double *)((char *)workspace + kWsPartialsOffset), res.npartials,
+                               (double)O * (double)T * (double)I, stats);
+        if (int rc = check_launch("trl_gae_fwd(stats)")) return rc;
+    }
+    if (npartials_out) *npartials_out = res.npartials;
+    g_kernel = res.kernel;
+    return TRL_OK;
+}
+
+
 extern "C" {
 
 int trl_abi_version(void) { return TRL_ABI_VERSION; }
@@ -130,46 +183,9 @@ int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward,
                 const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
                 int64_t O, int64_t T, int64_t I, void *advantage, void *value_target,
                 double *stats, void *workspace, size_t workspace_bytes, int algo) {
-    if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: bad dtype");
-    if (int rc = check_dims("trl_gae_fwd", O, T, I)) return rc;
-    if (!reward || !state_value || !done || !terminated || !advantage || !value_target)
-        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: null tensor pointer");
-    if (int rc = check_shifted("trl_gae_fwd", next_state_value, I, algo)) return rc;
-    if (lg_t && !gamma_t) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: lg_t given without gamma_t");
-    if (stats) {
-        if (!workspace || workspace_bytes < trl_workspace_bytes(O, T, I))
-            return fail(TRL_ERR_WORKSPACE, "trl_gae_fwd: stats requested but workspace is %zu bytes, need %zu",
-                        workspace_bytes, trl_workspace_bytes(O, T, I));
-        if (((uintptr_t)workspace & 7) != 0) return fail(TRL_ERR_WORKSPACE, "trl_gae_fwd: workspace must be 8-byte aligned");
-    }
-    GaeArgs a{reward, state_value, next_state_value, done, terminated, gamma_t, lg_t, gamma, lmbda, lg,
-              O, T, I, advantage, value_target, stats ? (double *)((char *)workspace + kWsPartialsOffset) : nullptr,
-              (mask_bcast && I > 1) ? 1 : 0};
-    hipStream_t s = (hipStream_t)stream;
-    if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ && algo != TRL_ALGO_LOCKSTEP)
-        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: unknown algo %d", algo);
-    LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
-    size_t lb_bytes = 0;
-    void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
-    if (algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I)) res = launch_gae_lockstep(s, val_dtype, coef_dtype, a);
-    if (res.status == TRL_ERR_UNSUPPORTED && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN))
-        res = launch_gae_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
-    if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
-        return fail(TRL_ERR_UNSUPPORTED, "trl_gae_fwd: SCAN family does not support this shape (needs I == 1)");
-    if (res.status == TRL_ERR_UNSUPPORTED && ((algo == TRL_ALGO_AUTO && lockstep_over_seq(O, I)) || algo == TRL_ALGO_LOCKSTEP))
-        res = launch_gae_lockstep(s, val_dtype, coef_dtype, a);
-    if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_LOCKSTEP)
-        return fail(TRL_ERR_UNSUPPORTED, "trl_gae_fwd: LOCKSTEP family needs 2 <= I <= 31");
-    if (res.status == TRL_ERR_UNSUPPORTED) res = launch_gae_seq(s, val_dtype, coef_dtype, a);
-    if (res.status != 0) return fail(res.status, "trl_gae_fwd: launch rejected (grid too large?)");
-    if (int rc = check_launch("trl_gae_fwd")) return rc;
-    if (stats) {
-        launch_reduce_partials(s, (const double *)((char *)workspace + kWsPartialsOffset), res.npartials,
-                               (double)O * (double)T * (double)I, stats);
-        if (int rc = check_launch("trl_gae_fwd(stats)")) return rc;
-    }
-    g_kernel = res.kernel;
-    return TRL_OK;
+    return gae_fwd_impl(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated, mask_bcast, gamma_t,
+                        lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, stats, workspace, workspace_bytes, algo,
+                        stats != nullptr, nullptr);
 }
 
 int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *next_state_value,
@@ -273,12 +289,31 @@ static int gae_normalize_impl(void *stream, int val_dtype, int coef_dtype, const
                                              "4 chunks per team (advantages are kept in registers)");
     }
     double *st = stats ? stats : (double *)((char *)workspace + kWsStatsOffset);
+    const int algo2 = algo == TRL_ALGO_FUSED ? TRL_ALGO_AUTO : algo;
+    if (!comm) {
+        // two launches: the scan writes its per-block moments, the scale pass sums them itself (every block, same fixed
+        // order as the reduction kernel: identical statistics) -- unless there are too many (SEQ family on many rows)
+        i64 np = 0;
+        if (int rc = gae_fwd_impl(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated, mask_bcast,
+                                  gamma_t, lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, nullptr, workspace,
+                                  workspace_bytes, algo2, true, &np))
+            return rc;
+        const double *partials = (const double *)((char *)workspace + kWsPartialsOffset);
+        if (np <= 4096) {
+            launch_normalize_from_partials(s, val_dtype, advantage, O * T * I, partials, np, (double)O * (double)T * (double)I, eps,
+                                           advantage, stats, 0);
+            if (int rc = check_launch("trl_gae_normalize_fwd(normalize)")) return rc;
+            g_kernel = "normalize";
+            return TRL_OK;
+        }
+        launch_reduce_partials(s, partials, np, (double)O * (double)T * (double)I, st);
+        if (int rc = check_launch("trl_gae_normalize_fwd(stats)")) return rc;
+        return trl_normalize(stream, val_dtype, advantage, O * T * I, st, eps, advantage);
+    }
     if (int rc = trl_gae_fwd(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated, mask_bcast,
-                             gamma_t, lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, st, workspace, workspace_bytes,
-                             algo == TRL_ALGO_FUSED ? TRL_ALGO_AUTO : algo))
+                             gamma_t, lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, st, workspace, workspace_bytes, algo2))
         return rc;
-    if (comm)
-        if (int rc = trl_xchg_allreduce_stats(stream, comm, st)) return rc;
+    if (int rc = trl_xchg_allreduce_stats(stream, comm, st)) return rc;
     return trl_normalize(stream, val_dtype, advantage, O * T * I, st, eps, advantage);
 }
 
@@ -325,9 +360,15 @@ int trl_standardize(void *stream, int dtype, const void *x, int64_t n, double ep
     if (!workspace || workspace_bytes < trl_workspace_bytes(n, 1, 1) || ((uintptr_t)workspace & 7))
         return fail(TRL_ERR_WORKSPACE, "trl_standardize: workspace is %zu bytes, need %zu (8-byte aligned)", workspace_bytes,
                     trl_workspace_bytes(n, 1, 1));
-    double *st = stats ? stats : (double *)((char *)workspace + kWsStatsOffset);
-    if (int rc = trl_moments(stream, dtype, x, n, st, workspace, workspace_bytes)) return rc;
-    return trl_normalize(stream, dtype, x, n, st, eps, out);
+    // two launches: per-block moments, then a scale pass whose blocks sum the (<= 2048) partials themselves
+    i64 np = 0;
+    double *partials = (double *)((char *)workspace + kWsPartialsOffset);
+    launch_moments((hipStream_t)stream, dtype, x, n, partials, &np);
+    if (int rc = check_launch("trl_standardize(moments)")) return rc;
+    launch_normalize_from_partials((hipStream_t)stream, dtype, x, n, partials, np, (double)n, eps, out, stats, 0);
+    if (int rc = check_launch("trl_standardize(normalize)")) return rc;
+    g_kernel = "normalize";
+    return TRL_OK;
 }
 
 int trl_standardize_grouped(void *stream, int dtype, const void *x, int64_t outer, int64_t G, int64_t inner, double eps, void *out,
