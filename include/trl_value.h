@@ -125,7 +125,7 @@ int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype,
  * Arguments as trl_gae_fwd; `advantage` receives the NORMALISED advantage.  `stats` (optional,
  * device double[3]) receives {N, sum(A), sum(A^2)} of the un-normalised advantage.
  * AUTO uses the single-launch FUSED kernel when the shape is eligible (I == 1, short rows, the
- * advantages fit in registers: up to 4 * #CUs * 1024 * V transitions), otherwise two launches
+ * advantages fit in registers: up to 8 * #CUs * 1024 * V transitions), otherwise two launches
  * (the scan writing per-block moments, a scale pass that sums them itself).  Single-GPU only: a batch sharded over GPUs uses trl_gae_fwd
  * (stats) -> all-reduce -> trl_normalize.
  */

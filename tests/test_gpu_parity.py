@@ -260,7 +260,7 @@ def test_errors_on_device():
 
 
 FUSED_SHAPES = [(64, 32, 1), (65536, 32, 1), (3000, 32, 1), (37, 100, 1), (5000, 100, 1), (33, 3, 1), (9, 1, 1),
-                (130, 128, 1), (2000, 1024, 1), (5, 7, 1)]
+                (130, 128, 1), (2000, 1024, 1), (5, 7, 1), (100000, 32, 1), (200000, 32, 1)]  # the last two: 5..8 chunks per team
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
@@ -270,6 +270,9 @@ def test_fused_gae_normalise_vs_oracle(shape, dtype):
     the returned moments against the unfused path.  Called twice: the in-launch exchange is epoch-tagged."""
     if shape[1] > 256 * (4 if dtype == torch.float32 else 2):
         pytest.skip("row longer than one chunk: not eligible for the fused kernel (covered by the fallback test)")
+    chunk = 256 * (4 if dtype == torch.float32 else 2)
+    if -(-shape[0] // (chunk // shape[1])) > 8 * 4 * torch.cuda.get_device_properties(0).multi_processor_count:
+        pytest.skip("more than 8 chunks per team: the advantages do not fit in registers (unfused route)")
     r, v, nv, done, term, gam, lp, lm = _rand_inputs(shape, dtype, seed=7)
     oadv, ovt = O.gae(0.99, 0.95, v, nv, r, done, term)
     onorm = O.normalize(oadv, 1e-4)

@@ -286,7 +286,7 @@ static int gae_normalize_impl(void *stream, int val_dtype, int coef_dtype, const
         if (res.status != TRL_ERR_UNSUPPORTED) return fail(res.status, "trl_gae_normalize_fwd: fused launch rejected");
         if (algo == TRL_ALGO_FUSED)
             return fail(TRL_ERR_UNSUPPORTED, "trl_gae_normalize_fwd: FUSED family needs I == 1, T <= 256*V and at most "
-                                             "4 chunks per team (advantages are kept in registers)");
+                                             "8 chunks per team (advantages are kept in registers; 4 for fp32 values with fp64 coefficients)");
     }
     double *st = stats ? stats : (double *)((char *)workspace + kWsStatsOffset);
     const int algo2 = algo == TRL_ALGO_FUSED ? TRL_ALGO_AUTO : algo;

@@ -325,7 +325,10 @@ LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *w
     const i64 nchunks = (a.O + R - 1) / R;
     const i64 per_iter = (i64)G * kTeams;
     const i64 k_needed = (nchunks + per_iter - 1) / per_iter;
-    if (k_needed > 4) return LaunchResult{2, 0, nullptr};  // advantages would not fit in registers
+    // the advantages of K chunks stay in registers: K = 8 fits the 128 VGPRs of a 1024-thread block except for fp32 values
+    // with fp64 coefficients (spills)
+    constexpr bool kMixed = sizeof(typename Op::TS) == 4 && sizeof(typename Op::TC) == 8;
+    if (k_needed > (kMixed ? 4 : 8)) return LaunchResult{2, 0, nullptr};
     const bool al = aligned16(a.reward) && (!a.next_value || aligned16(a.value)) && aligned16(a.next_value) && aligned16(a.done) &&
                     aligned16(a.terminated) && aligned16(a.gamma_t) && aligned16(a.lg_t) && aligned16(a.advantage) &&
                     aligned16(a.value_target);
@@ -335,7 +338,12 @@ LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *w
     const dim3 grid((unsigned)G), block(kFusedThreads);
     FusedWs *w = (FusedWs *)ws;
 #define TRL_FUSED(VEC, WI, KK) hipLaunchKernelGGL((gae_fused_kernel<Op, VEC, WI, KK>), grid, block, 0, s, a, geo, w, stats_out, xd)
-#define TRL_FUSED_K(VEC, WI) do { if (k_needed <= 2) TRL_FUSED(VEC, WI, 2); else TRL_FUSED(VEC, WI, 4); } while (0)
+#define TRL_FUSED_K(VEC, WI)                                     \
+    do {                                                         \
+        if (k_needed <= 2) TRL_FUSED(VEC, WI, 2);                \
+        else if (k_needed <= 4) TRL_FUSED(VEC, WI, 4);           \
+        else if constexpr (!kMixed) TRL_FUSED(VEC, WI, 8);       \
+    } while (0)
     if (vec) { if (wi) TRL_FUSED_K(true, true); else TRL_FUSED_K(true, false); }
     else     { if (wi) TRL_FUSED_K(false, true); else TRL_FUSED_K(false, false); }
 #undef TRL_FUSED_K
