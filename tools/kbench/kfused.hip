@@ -27,8 +27,8 @@ void run(const char* name, GaeArgs a, FusedGeom geo, FusedWs* ws, int G, int ite
 int main() {
     float *r, *v, *nv, *o1, *o2; unsigned char *d, *t; FusedWs* ws;
     CK(hipMalloc(&r, N * 4)); CK(hipMalloc(&v, N * 4)); CK(hipMalloc(&nv, N * 4));
-    CK(hipMalloc(&o1, N * 4)); CK(hipMalloc(&o2, N * 4)); CK(hipMalloc(&d, N)); CK(hipMalloc(&t, N)); CK(hipMalloc(&ws, 8 << 20));
-    CK(hipMemset(ws, 0, 8 << 20));
+    CK(hipMalloc(&o1, N * 4)); CK(hipMalloc(&o2, N * 4)); CK(hipMalloc(&d, N)); CK(hipMalloc(&t, N)); CK(hipMalloc(&ws, 64 << 20));  // 4 slot replicas x 256 blocks x the widest stride tried below (16.5 KB) = 16.9 MB
+    CK(hipMemset(ws, 0, 64 << 20));
     std::vector<float> h(N); for (i64 i = 0; i < N; ++i) h[i] = (float)rand() / (float)RAND_MAX - 0.5f;
     CK(hipMemcpy(r, h.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(v, h.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(nv, h.data(), N * 4, hipMemcpyHostToDevice));
     std::vector<unsigned char> hm(N); for (i64 i = 0; i < N; ++i) hm[i] = (rand() % 100) == 0;
@@ -41,6 +41,7 @@ int main() {
         run<0, 2>("full (product)", a, geo, ws, G, 500);
         run<4, 2>("last vt deferred", a, geo, ws, G, 500);
         run<1, 2>("no gather", a, geo, ws, G, 500);
+        run<10, 2>("both chunks' loads up front", a, geo, ws, G, 500);
     }
     for (int stride : {16, 32, 64, 128, 512, 528, 1024, 2064}) {   // slot line spacing: 128 B .. 16 KB (memory-channel spreading)
         geo.slot_stride = stride;
