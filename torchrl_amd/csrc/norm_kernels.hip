@@ -187,6 +187,14 @@ __global__ __launch_bounds__(kRedThreads) void normalize_grouped_kernel(const TS
     }
     __syncthreads();
     const i64 stride = (i64)gridDim.x * kRedThreads;
+    if (n <= 0x7fffffffLL) {  // 32-bit index math: the 64-bit divisions dominated this kernel (7.4 us at [4096x100x5])
+        const unsigned n32 = (unsigned)n, G32 = (unsigned)G, in32 = (unsigned)inner, st32 = (unsigned)stride;
+        for (unsigned f = blockIdx.x * kRedThreads + threadIdx.x; f < n32; f += st32) {
+            const unsigned g = in32 == 1 ? f % G32 : (f / in32) % G32;
+            out[f] = (x[f] - tab[2 * g]) / tab[2 * g + 1];
+        }
+        return;
+    }
     for (i64 f = (i64)blockIdx.x * kRedThreads + threadIdx.x; f < n; f += stride) {
         const i64 g = (f / inner) % G;
         out[f] = (x[f] - tab[2 * g]) / tab[2 * g + 1];
