@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TRL_ABI_VERSION 4
+#define TRL_ABI_VERSION 5
 
 enum { TRL_F32 = 0, TRL_F64 = 1 };
 
@@ -158,6 +158,25 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype,
                       void *returns, void *workspace, size_t workspace_bytes, int algo);
 
 /*
+ * TD(1) return.
+ * Replaces: td1_return_estimate (functional.py:464-562); vec_td1_return_estimate is vec TD(lambda) at lmbda = 1
+ *           (functional.py:691-700) and goes through trl_td_lambda_fwd.
+ *   dnt_t = done_t & ~terminated_t;  g = v'_{T-1}  (the raw next value, not masked)
+ *   for t = T-1..0:  g = R_t = r_t + (gamma_t*(1-terminated_t)) * ((1-dnt_t)*g + dnt_t*v'_t)
+ * gamma_t: optional per-element tensor (coef_dtype), else the scalar `gamma` (already rounded to the value dtype:
+ *   the reference builds torch.full_like(next_state_value, gamma)).
+ * rolling_gamma == 0 (needs gamma_t): the O(T^2) variant (functional.py:550-561): R_k reruns the tail T-1..k with
+ *   gamma_k held fixed and g starting from 0 -- unlike TD(lambda)'s, it does NOT bootstrap from v'_{T-1}.
+ * workspace: optional (NULL, 0), see trl_workspace_bytes.
+ */
+int trl_td1_fwd(void *stream, int val_dtype, int coef_dtype,
+                const void *reward, const void *next_state_value,
+                const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                const void *gamma_t, double gamma, int rolling_gamma,
+                int64_t O, int64_t T, int64_t I,
+                void *returns, void *workspace, size_t workspace_bytes, int algo);
+
+/*
  * V-trace advantage and targets.
  * Replaces: vtrace_advantage_estimate (functional.py:1270-1350).
  *   rho = exp(log_pi - log_mu); rb = min(rho, rho_thresh); cb = min(rho, c_thresh)
@@ -165,6 +184,9 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype,
  *   vs = x + v;  vs+_t = vs_{t+1} (t < T-1), v'_{T-1} (t = T-1; the shift ignores done)
  *   advantage = rb*(r + gamma*(1-term)*vs+ - v)
  * Outputs have dtype promote(val_dtype, coef_dtype) (the reference allocates nothing in val_dtype).
+ * rho_thresh_t / c_thresh_t (ABI 5): optional per-element thresholds (val_dtype, (O, T, I)) for callers that pass a
+ *   broadcastable threshold TENSOR (functional.py:1311-1330: rho.clamp_max(tensor)); they replace the scalars and run
+ *   on the SEQ family (AUTO picks it; any other `algo` is TRL_ERR_UNSUPPORTED).  NULL: the scalars apply.
  * workspace: optional (NULL, 0), see trl_workspace_bytes.
  */
 int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype,
@@ -172,8 +194,62 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype,
                    const void *state_value, const void *next_state_value, const void *reward,
                    const uint8_t *done, const uint8_t *terminated, int mask_bcast,
                    const void *gamma_t, double gamma, double rho_thresh, double c_thresh,
+                   const void *rho_thresh_t, const void *c_thresh_t,
                    int64_t O, int64_t T, int64_t I,
                    void *advantage, void *vs, void *workspace, size_t workspace_bytes, int algo);
+
+/*
+ * Backward passes (adjoints) of the four estimators: what autograd through the reference's Python loops computes when
+ * the estimators run with differentiable=True (torchrl/objectives/utils.py:74-83 builds every loss's estimator that
+ * way; test/test_cost.py:15521-15584 asserts the gradient reaching `reward`).  The adjoint of the reverse scan
+ * x_t = b_t + a_t x_{t+1} is the forward scan G_t = gbar_t + a_{t-1} G_{t-1}; the kernels read the incoming gradients
+ * and the masks / coefficients once and write every requested gradient once (no flipped or shifted copies).
+ * Conventions: incoming gradients may be NULL (= zeros) but not all of them; outputs may be NULL (not written) but not
+ * all of them; masks, gamma_t / lg_t / lmbda_t, the scalars, mask_bcast, O / T / I and `algo` (AUTO, SCAN: I == 1, SEQ:
+ * any shape) as in the forward call.  Gradients w.r.t. value tensors have val_dtype.  workspace: optional look-back
+ * region as in the forward calls.
+ *
+ * trl_gae_bwd: gbar = grad_advantage + grad_value_target, a_t = lg_t (1 - done_t);
+ *   d_reward = G,  d_state_value = grad_value_target - G,  d_next_state_value = G * gamma_t * (1 - terminated_t).
+ *   (d_reward is the adjoint itself: the host forms gradients w.r.t. gamma / lmbda tensors from it.)
+ */
+int trl_gae_bwd(void *stream, int val_dtype, int coef_dtype,
+                const void *grad_advantage, const void *grad_value_target,
+                const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
+                int64_t O, int64_t T, int64_t I,
+                void *d_reward, void *d_state_value, void *d_next_state_value,
+                void *workspace, size_t workspace_bytes, int algo);
+/* trl_td_lambda_bwd (rolling gamma only): a_t = gamma_t lmbda_t (1 - done_t);  d_reward = G,
+ *   d_next_state_value_t = (G_t gamma_t ((1 - lmbda_t) + lmbda_t done_t) + [t = T-1] a_t G_t) (1 - terminated_t). */
+int trl_td_lambda_bwd(void *stream, int val_dtype, int coef_dtype, const void *grad_returns,
+                      const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                      const void *gamma_t, const void *lmbda_t, double gamma, double lmbda,
+                      int64_t O, int64_t T, int64_t I,
+                      void *d_reward, void *d_next_state_value,
+                      void *workspace, size_t workspace_bytes, int algo);
+/* trl_td1_bwd (rolling gamma only): gnt = gamma_t (1 - terminated_t), dnt = done & ~terminated, a_t = gnt_t (1 - dnt_t);
+ *   d_reward = G,  d_next_state_value_t = G_t gnt_t dnt_t + [t = T-1] a_t G_t. */
+int trl_td1_bwd(void *stream, int val_dtype, int coef_dtype, const void *grad_returns,
+                const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                const void *gamma_t, double gamma,
+                int64_t O, int64_t T, int64_t I,
+                void *d_reward, void *d_next_state_value,
+                void *workspace, size_t workspace_bytes, int algo);
+/* trl_vtrace_bwd: grad_advantage / grad_vs and `vs` (the forward call's second output, saved) have dtype
+ *   promote(val_dtype, coef_dtype); gradients w.r.t. log_pi, log_mu (= -d_log_pi), state_value, next_state_value, reward
+ *   have val_dtype; d_gamma_t (optional, per element) has the promoted dtype.  The clipped branches of min(rho, thresh)
+ *   pass no gradient (torch.clamp_max). */
+int trl_vtrace_bwd(void *stream, int val_dtype, int coef_dtype,
+                   const void *grad_advantage, const void *grad_vs,
+                   const void *log_pi, const void *log_mu,
+                   const void *state_value, const void *next_state_value, const void *reward, const void *vs,
+                   const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                   const void *gamma_t, double gamma, double rho_thresh, double c_thresh,
+                   const void *rho_thresh_t, const void *c_thresh_t,
+                   int64_t O, int64_t T, int64_t I,
+                   void *d_log_pi, void *d_log_mu, void *d_state_value, void *d_next_state_value, void *d_reward,
+                   void *d_gamma_t, void *workspace, size_t workspace_bytes, int algo);
 
 /*
  * Advantage normalisation from precomputed statistics.

@@ -128,6 +128,53 @@ void FN(oracle_td_lambda_)(const TS *reward, const TS *next_value,
 }
 
 /* ---------------------------------------------------------------------------
+ * TD(1) return -- functional.py:515-562 (td1_return_estimate)
+ *   gamma -> full tensor (:527-529, torch.full_like(nsv, gamma): TG == TS for python floats)
+ *   dnt = done & ~terminated                                            (:538)
+ *   rolling (:539-549):
+ *     gamma = gamma * not_terminated; g = nsv[T-1]   (the RAW next value, not masked)
+ *     for i reversed: g = ret[i] = r[i] + gamma[i]*((1-dnt)*g + dnt*nsv[i])
+ *   not rolling (:550-561): for every start k, g = 0 (python int: NO bootstrap from
+ *     nsv[T-1]), gamma[k]*not_terminated[i] held fixed over the tail:
+ *     for i reversed down to k: g = r[i] + (gamma[k]*nt[i])*((1-dnt)*g + dnt*nsv[i])
+ * ------------------------------------------------------------------------- */
+void FN(oracle_td1_)(const TS *reward, const TS *next_value,
+                     const unsigned char *done, const unsigned char *terminated,
+                     const TG *gamma_t, double gamma, int rolling,
+                     long O, long T, long I, TS *returns)
+{
+    for (long o = 0; o < O; ++o) {
+        for (long i = 0; i < I; ++i) {
+            if (rolling) {
+                TC g = (TC)next_value[(o * T + (T - 1)) * I + i];
+                for (long t = T - 1; t >= 0; --t) {
+                    long j = (o * T + t) * I + i;
+                    TG gnt = (gamma_t ? gamma_t[j] : (TG)gamma) * (TG)(terminated[j] ? 0 : 1);
+                    int dnt = (done[j] && !terminated[j]) ? 1 : 0;
+                    TC mix = (TC)(1 - dnt) * g + (TC)((TS)dnt * next_value[j]);
+                    g = (TC)reward[j] + (TC)gnt * mix;
+                    returns[j] = (TS)g;
+                }
+            } else {
+                for (long k = 0; k < T; ++k) {
+                    long jk = (o * T + k) * I + i;
+                    TG gk = gamma_t ? gamma_t[jk] : (TG)gamma;
+                    TC g = (TC)0;
+                    for (long t = T - 1; t >= k; --t) {
+                        long j = (o * T + t) * I + i;
+                        TG gnt = gk * (TG)(terminated[j] ? 0 : 1);
+                        int dnt = (done[j] && !terminated[j]) ? 1 : 0;
+                        TC mix = (TC)(1 - dnt) * g + (TC)((TS)dnt * next_value[j]);
+                        g = (TC)reward[j] + (TC)gnt * mix;
+                    }
+                    returns[jk] = (TS)g;
+                }
+            }
+        }
+    }
+}
+
+/* ---------------------------------------------------------------------------
  * V-trace -- functional.py:1306-1350 (vtrace_advantage_estimate)
  *   done_discounts = gamma*not_done, terminated_discounts = gamma*not_term (:1322-1323, TG)
  *   rho = exp(log_pi - log_mu); clipped_rho = min(rho, rho_thresh)         (:1325-1326)
@@ -143,6 +190,7 @@ static inline TC FN(clamp_max_)(TC x, TC hi) { return (x != x) ? x : (x > hi ? h
 void FN(oracle_vtrace_)(const TS *log_pi, const TS *log_mu, const TS *value, const TS *next_value,
                         const TS *reward, const unsigned char *done, const unsigned char *terminated,
                         const TG *gamma_t, double gamma, double rho_thresh, double c_thresh,
+                        const TS *rho_t, const TS *c_t,
                         long O, long T, long I, TC *advantage, TC *vs_out)
 {
     for (long o = 0; o < O; ++o) {
@@ -157,8 +205,9 @@ void FN(oracle_vtrace_)(const TS *log_pi, const TS *log_mu, const TS *value, con
                 TS lr = log_pi[j] - log_mu[j];
                 TS rho = (sizeof(TS) == 4) ? (TS)expf((float)lr) : (TS)exp((double)lr);
                 /* thresholds are 0-dim tensors in the reference: they do not promote rho */
-                TS crho = (TS)FN(clamp_max_)((TC)rho, (TC)(TS)rho_thresh);
-                TS cc = (TS)FN(clamp_max_)((TC)rho, (TC)(TS)c_thresh);
+                /* rho_t / c_t: a threshold TENSOR broadcast to the inputs (rho.clamp_max(tensor), :1326-1330) */
+                TS crho = (TS)FN(clamp_max_)((TC)rho, (TC)(rho_t ? rho_t[j] : (TS)rho_thresh));
+                TS cc = (TS)FN(clamp_max_)((TC)rho, (TC)(c_t ? c_t[j] : (TS)c_thresh));
                 TC delta = (TC)crho * (((TC)reward[j] + (TC)td * (TC)next_value[j]) - (TC)value[j]);
                 x = delta + ((TC)dd * (TC)cc) * x;
                 TC vs = x + (TC)value[j];

@@ -10,15 +10,18 @@ DT = {"f32": torch.float32, "f64": torch.float64}
 
 with open(os.path.join(GOLDEN, "manifest.json")) as _f:
     MANIFEST = json.load(_f)
+with open(os.path.join(GOLDEN, "manifest_next.json")) as _f:  # tools/gen_golden_next.py: td0 / td1 / reward2go, gradients, ...
+    MANIFEST.update({k: v for k, v in json.load(_f).items() if isinstance(v, list)})
 _npz = {}
 
 
-def cases(family):
-    return MANIFEST[family]
+def cases(family, fn=None):
+    """Cases of a fixture family; ``fn`` filters on the case's ``fn`` field (families that hold several functions)."""
+    return [c for c in MANIFEST[family] if fn is None or c.get("fn") == fn]
 
 
-def ids(family):
-    return [f"{family}-{c['id']}" for c in MANIFEST[family]]
+def ids(family, fn=None):
+    return [f"{family}-{c['id']}" for c in cases(family, fn)]
 
 
 def arrays(family, case):
@@ -31,7 +34,9 @@ def arrays(family, case):
 
 def coef(meta, arrs, name):
     """Rebuild gamma / lmbda exactly as it was handed to the reference."""
-    m = meta[name]
+    m = meta.get(name)
+    if m is None:
+        return None
     if m["kind"] == "float":
         return m["value"]
     return arrs[name]

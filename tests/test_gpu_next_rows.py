@@ -1,0 +1,123 @@
+"""GPU (-m gpu): the "next" rows of SURVEY.md 8(f).2 -- td0_*, td1_*, vec_td1_*, reward2go -- and V-trace with threshold
+tensors, through the HIP path, against golden fixtures generated from the imported reference (tools/gen_golden_next.py)
+and against the CPU oracle.  Bars: SEQ family bit-identical to the reference loops; SCAN / LOCKSTEP fp32 rtol=atol=1e-5,
+fp64 1e-12; the reference's own vec variants (truncated filters) at the reference's test tolerance 1e-4."""
+import pytest
+import torch
+
+import golden_util as G
+from oracle import value_oracle as O
+from torchrl_amd.objectives.value import functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SEQ, SCAN, LOCKSTEP = F.ALGO_SEQ, F.ALGO_SCAN, F.ALGO_LOCKSTEP
+
+
+def tol(dtype):
+    return dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-12, atol=1e-12)
+
+
+def cu(x):
+    return x.to(DEV) if isinstance(x, torch.Tensor) else x
+
+
+def check(out, ref, exact):
+    out = out.cpu()
+    assert out.dtype == ref.dtype and out.shape == ref.shape
+    if exact:
+        assert torch.equal(out, ref), f"max abs diff {(out - ref).abs().max().item()}"
+    else:
+        torch.testing.assert_close(out, ref, **tol(ref.dtype))
+
+
+@pytest.mark.parametrize("meta", G.cases("td", "td0"), ids=G.ids("td", "td0"))
+def test_td0_golden(meta):
+    a = G.arrays("td", meta)
+    ret = F.td0_return_estimate(meta["gamma"], cu(a["next_state_value"]), cu(a["reward"]), cu(a["terminated"]))
+    check(ret, a["returns"], True)
+    adv = F.td0_advantage_estimate(meta["gamma"], cu(a["state_value"]), cu(a["next_state_value"]), cu(a["reward"]), cu(a["done"]),
+                                   cu(a["terminated"]))
+    check(adv, a["advantage"], True)
+
+
+def td1_algos(call):
+    chunk = 256 * (4 if call.vdt == torch.float32 else 2)
+    if not call.rolling:
+        return [SEQ]
+    out = [SEQ, SCAN] if (call.I == 1 or call.T * call.I <= chunk) else [SEQ]
+    if 2 <= call.I <= 31:
+        out.append(LOCKSTEP)
+    return out
+
+
+@pytest.mark.parametrize("meta", G.cases("td", "td1"), ids=G.ids("td", "td1"))
+def test_td1_golden(meta):
+    """td1_return_estimate: rolling and rolling_gamma=False (which starts from g = 0, functional.py:550-561), masks where
+    terminated is not a subset of done, every kernel family that takes the shape."""
+    a = G.arrays("td", meta)
+    gamma = cu(G.coef(meta, a, "gamma"))
+    args = (cu(a["next_state_value"]), cu(a["reward"]), cu(a["done"]), cu(a["terminated"]))
+    call = F._prepare_td1(gamma, *args, meta["rolling_gamma"], meta["time_dim"])
+    for algo in td1_algos(call):
+        ret = F._launch_td1(call, a["returns"].dtype, algo=algo)
+        fam = F.last_kernel()
+        assert ("seq" in fam) == (algo == SEQ), fam
+        check(ret, a["returns"], algo == SEQ)
+    ret = F.td1_return_estimate(gamma, *args, meta["rolling_gamma"], **G.time_kw(meta))
+    check(ret, a["returns"], False)
+    if "advantage" in a:
+        adv = F.td1_advantage_estimate(gamma, cu(a["state_value"]), *args, meta["rolling_gamma"], time_dim=meta["time_dim"])
+        check(adv, a["advantage"], False)
+    if "vec_returns" in a:  # the reference's vec variant is filter-truncated: its own tests compare at 1e-4
+        vec = F.vec_td1_return_estimate(gamma, *args, meta["rolling_gamma"], time_dim=meta["time_dim"])
+        torch.testing.assert_close(vec.cpu(), a["vec_returns"], rtol=1e-4, atol=1e-4)
+        vadv = F.vec_td1_advantage_estimate(gamma, cu(a["state_value"]), *args, meta["rolling_gamma"], time_dim=meta["time_dim"])
+        torch.testing.assert_close(vadv.cpu(), a["vec_returns"] - a["state_value"], rtol=1e-4, atol=1e-4)
+
+
+def test_td1_not_rolling_needs_gamma_tensor():
+    r = torch.randn(3, 8, 1, device=DEV)
+    d = torch.zeros(3, 8, 1, dtype=torch.bool, device=DEV)
+    with pytest.raises(RuntimeError, match="rolling_gamma=False is expected only with time-sensitive gamma values"):
+        F.td1_return_estimate(0.9, r, r, d, rolling_gamma=False)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", [(300, 32, 1), (37, 100, 1), (3, 2500, 1), (2, 4099, 1), (40, 50, 5), (19, 101, 3), (4, 300, 130)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_td1_vs_oracle(shape, dtype):
+    g = torch.Generator().manual_seed(31)
+    r, nv = (torch.randn(shape, generator=g, dtype=torch.float32).to(dtype) for _ in range(2))
+    term = torch.rand(shape, generator=g) < 0.02
+    done = term | (torch.rand(shape, generator=g) < 0.02)
+    gam = (0.9 + 0.1 * torch.rand(shape, generator=g)).to(dtype)
+    for gamma in (0.99, gam):
+        want = O.td1(gamma, nv, r, done, term)
+        call = F._prepare_td1(cu(gamma), cu(nv), cu(r), cu(done), cu(term), None, -2)
+        for algo in td1_algos(call):
+            check(F._launch_td1(call, dtype, algo=algo), want, algo == SEQ)
+        check(F.td1_return_estimate(cu(gamma), cu(nv), cu(r), cu(done), cu(term)), want, False)
+    if shape[1] <= 101:  # O(T^2)
+        want = O.td1(gam, nv, r, done, term, False)
+        check(F.td1_return_estimate(cu(gam), cu(nv), cu(r), cu(done), cu(term), False), want, True)
+
+
+@pytest.mark.parametrize("meta", G.cases("td", "reward2go"), ids=G.ids("td", "reward2go"))
+def test_reward2go_golden(meta):
+    a = G.arrays("td", meta)
+    kw = {} if meta["time_dim"] == -2 else {"time_dim": meta["time_dim"]}
+    out = F.reward2go(cu(a["reward"]), cu(a["done"]), meta["gamma"], **kw)
+    check(out, a["out"], False)
+
+
+@pytest.mark.parametrize("meta", G.cases("vtrace_thresh"), ids=G.ids("vtrace_thresh"))
+def test_vtrace_threshold_tensors_golden(meta):
+    """rho.clamp_max(tensor) with broadcastable threshold tensors (functional.py:1311-1330)."""
+    a = G.arrays("vtrace_thresh", meta)
+    adv, vs = F.vtrace_advantage_estimate(meta["gamma"], cu(a["log_pi"]), cu(a["log_mu"]), cu(a["state_value"]),
+                                          cu(a["next_state_value"]), cu(a["reward"]), cu(a["done"]), cu(a["terminated"]),
+                                          cu(a["rho_thresh"]), cu(a["c_thresh"]), time_dim=meta["time_dim"])
+    assert F.last_kernel() == "vtrace_seq"
+    check(adv, a["advantage"], False)
+    check(vs, a["vs"], False)

@@ -172,7 +172,7 @@ def test_multifeature_vs_oracle(shape, time_dim, dtype):
         for algo in algos(gcall):
             adv, vt, st = F._launch_gae(gcall, want_stats=True, algo=algo)
             if algo == SCAN:
-                assert "interleaved" in F.last_kernel() or True
+                assert "interleaved" in F.last_kernel(), F.last_kernel()
             check(adv, oadv, algo == SEQ, done)
             check(vt, ovt, algo == SEQ, done)
             a64 = adv.double()
@@ -226,20 +226,6 @@ def test_reward2go_closed_form():
     out = F.reward2go(reward, done, 0.99, time_dim=-1)
     exp = torch.tensor([3.9404, 2.9701, 1.9900, 1.0, 3.9404, 2.9701, 1.9900, 1.0, 1.9900, 1.0], device=DEV).view(1, 10)
     torch.testing.assert_close(out, exp, rtol=1e-4, atol=1e-4)
-
-
-def test_td1_matches_reference_semantics():
-    r, v, nv, done, term, gam, lp, lm = _rand_inputs((5, 40, 1), torch.float32, seed=21)
-    out = F.td1_return_estimate(0.97, cu(nv), cu(r), cu(done), cu(term)).cpu()
-    # reference loop, functional.py:538-549, restated inline for this small case
-    g = nv[:, -1].clone()
-    exp = torch.empty_like(r)
-    dnt = (done & ~term).float()
-    gnt = 0.97 * (~term).float()
-    for i in reversed(range(40)):
-        g = r[:, i] + gnt[:, i] * ((1 - dnt[:, i]) * g + dnt[:, i] * nv[:, i])
-        exp[:, i] = g
-    torch.testing.assert_close(out, exp, rtol=1e-5, atol=1e-5)
 
 
 def test_errors_on_device():

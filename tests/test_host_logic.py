@@ -140,8 +140,8 @@ def test_expanded_masks_are_handed_over_compact():
     for dd, tt in ((d, full), (full, full)):
         c = F._prepare_gae(0.9, 0.9, r, r, r, dd, tt, -3)
         assert c.mask_bcast == 0 and c.done.shape == r.shape and c.done.is_contiguous() and c.done.dtype == torch.uint8
-    rg = r.clone().requires_grad_(True)
-    assert F._prepare_gae(0.9, 0.9, rg, r, r, d, d, -3).mask_bcast == 0
+    rg = r.clone().requires_grad_(True)  # differentiable calls keep the compact masks: the backward kernels read them in place
+    assert F._prepare_gae(0.9, 0.9, rg, r, r, d, d, -3).mask_bcast == 1
     # I == 1: nothing to broadcast over
     assert F._prepare_gae(0.9, 0.9, r[:, :, :1], r[:, :, :1], r[:, :, :1], base, base, -3).mask_bcast == 0
 
@@ -152,18 +152,6 @@ def test_vtrace_thresholds_round_like_torch_tensor():
     c = F._prepare_vtrace(0.99, r, r, r, r, r, d, None, 0.7, 0.3, -2)
     assert c.rho_thresh == float(torch.tensor(0.7)) and c.c_thresh == float(torch.tensor(0.3))
     assert c.terminated.data_ptr() == c.done.data_ptr() or torch.equal(c.terminated, c.done)
-
-
-def test_transpose_time_decorator_contract():
-    @F._transpose_time
-    def f(x, *, time_dim=-2):
-        return x * 2
-
-    x = torch.randn(3, 4, 5)
-    assert f(x, time_dim=-3).shape == x.shape
-    assert f(torch.randn(7), time_dim=-1).shape == (7,)
-    with pytest.raises(RuntimeError, match="not compatible"):
-        f(torch.randn(7), time_dim=-3)
 
 
 def test_library_binds_to_torchs_hip_runtime_whatever_the_import_order():

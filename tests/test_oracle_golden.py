@@ -80,3 +80,58 @@ def test_oracle_vs_reference_live(dtype, shape, time_dim):
     tol = dict(rtol=2e-6, atol=2e-6) if dtype == torch.float32 else dict(rtol=1e-14, atol=1e-14)
     torch.testing.assert_close(adv, oadv, **tol)
     torch.testing.assert_close(vs, ovs, **tol)
+
+
+# ---- "next" rows: TD(0), TD(1), reward2go; V-trace with threshold tensors (tools/gen_golden_next.py) ----
+@pytest.mark.parametrize("meta", G.cases("td", "td0"), ids=G.ids("td", "td0"))
+def test_td0_bit_exact(meta):
+    a = G.arrays("td", meta)
+    ret = O.td0(meta["gamma"], a["next_state_value"], a["reward"], a["terminated"])
+    assert ret.dtype == a["returns"].dtype and torch.equal(ret, a["returns"])
+    assert torch.equal(ret - a["state_value"], a["advantage"])
+
+
+@pytest.mark.parametrize("meta", G.cases("td", "td1"), ids=G.ids("td", "td1"))
+def test_td1_bit_exact(meta):
+    """Rolling and rolling_gamma=False loops (functional.py:539-561), incl. masks where terminated is not a subset of done."""
+    a = G.arrays("td", meta)
+    ret = O.td1(G.coef(meta, a, "gamma"), a["next_state_value"], a["reward"], a["done"], a["terminated"], meta["rolling_gamma"],
+                **G.time_kw(meta))
+    assert ret.dtype == a["returns"].dtype
+    assert torch.equal(ret, a["returns"])
+    if "advantage" in a:
+        assert torch.equal(ret - a["state_value"], a["advantage"])
+
+
+@pytest.mark.parametrize("meta", G.cases("td", "reward2go"), ids=G.ids("td", "reward2go"))
+def test_reward2go(meta):
+    """The reference convolves with a truncated geometric filter: the sequential restatement agrees to rounding."""
+    a = G.arrays("td", meta)
+    out = O.reward2go(a["reward"], a["done"], meta["gamma"], **({} if meta["time_dim"] == -2 else {"time_dim": meta["time_dim"]}))
+    assert out.shape == a["out"].shape and out.dtype == a["out"].dtype
+    tol = dict(rtol=2e-6, atol=2e-6) if out.dtype == torch.float32 else dict(rtol=1e-13, atol=1e-13)
+    torch.testing.assert_close(out, a["out"], **tol)
+
+
+@pytest.mark.parametrize("meta", G.cases("vtrace_thresh"), ids=G.ids("vtrace_thresh"))
+def test_vtrace_threshold_tensors(meta):
+    a = G.arrays("vtrace_thresh", meta)
+    adv, vs = O.vtrace(meta["gamma"], a["log_pi"], a["log_mu"], a["state_value"], a["next_state_value"], a["reward"], a["done"],
+                       a["terminated"], a["rho_thresh"], a["c_thresh"], time_dim=meta["time_dim"])
+    tol = dict(rtol=2e-6, atol=2e-6) if adv.dtype == torch.float32 else dict(rtol=1e-14, atol=1e-14)
+    torch.testing.assert_close(adv, a["advantage"], **tol)
+    torch.testing.assert_close(vs, a["vs"], **tol)
+
+
+def test_td1_vs_reference_live():
+    F = _ref()
+    g = torch.Generator().manual_seed(9)
+    for dtype in (torch.float32, torch.float64):
+        for shape, time_dim in (((7, 50, 1), -2), ((4, 30, 3, 1), -3)):
+            r, nv = (torch.randn(shape, generator=g, dtype=dtype) for _ in range(2))
+            term = torch.rand(shape, generator=g) < 0.1
+            done = torch.rand(shape, generator=g) < 0.1
+            gam = (0.5 + 0.5 * torch.rand(shape, generator=g)).to(dtype)
+            for gamma, rolling in ((0.97, None), (gam, True), (gam, False)):
+                ref = F.td1_return_estimate(gamma, nv, r, done, term, rolling, time_dim=time_dim)
+                assert torch.equal(ref, O.td1(gamma, nv, r, done, term, rolling, time_dim=time_dim))

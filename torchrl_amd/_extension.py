@@ -18,7 +18,7 @@ import warnings
 
 _LIB_NAME = "libtrl_value.so"
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EXTENSION_WARNING = (
     f"Failed to load the torchrl_amd HIP library ({_LIB_PATH}). The value estimators "
@@ -50,8 +50,18 @@ _PROTOTYPES = {
                                      _i64, _i64, _i64, _vp, _vp, _dbl, _vp, _vp, _sz, _int]),
     "trl_td_lambda_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _int,
                                  _i64, _i64, _i64, _vp, _vp, _sz, _int]),
-    "trl_vtrace_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _dbl, _dbl, _dbl,
+    "trl_td1_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _int, _vp, _dbl, _int,
+                           _i64, _i64, _i64, _vp, _vp, _sz, _int]),
+    "trl_vtrace_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _dbl, _dbl, _dbl, _vp, _vp,
                               _i64, _i64, _i64, _vp, _vp, _vp, _sz, _int]),
+    "trl_gae_bwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _dbl,
+                           _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _int]),
+    "trl_td_lambda_bwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl,
+                                 _i64, _i64, _i64, _vp, _vp, _vp, _sz, _int]),
+    "trl_td1_bwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _int, _vp, _dbl,
+                           _i64, _i64, _i64, _vp, _vp, _vp, _sz, _int]),
+    "trl_vtrace_bwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _dbl, _dbl, _dbl, _vp, _vp,
+                              _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int]),
     "trl_normalize": (_int, [_vp, _int, _vp, _i64, _vp, _dbl, _vp]),
     "trl_moments": (_int, [_vp, _int, _vp, _i64, _vp, _vp, _sz]),
     "trl_standardize": (_int, [_vp, _int, _vp, _i64, _dbl, _vp, _vp, _vp, _sz]),

@@ -158,6 +158,96 @@ static int gae_fwd_impl(void *stream, int val_dtype, int coef_dtype, const void 
 }
 
 
+// ---- backward entry points (bwd_kernels.hip) ----------------------------------------------------------------------------------
+// family selection shared by the four: SCAN (I == 1) unless SEQ is asked for; SEQ for every other shape
+template <class ScanFn, class SeqFn>
+static int bwd_dispatch(const char *fn, int algo, ScanFn &&scan, SeqFn &&seq) {
+    if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ) return fail(TRL_ERR_INVALID_ARGUMENT, "%s: unknown algo %d", fn, algo);
+    LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
+    if (algo != TRL_ALGO_SEQ) res = scan();
+    if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN) return fail(TRL_ERR_UNSUPPORTED, "%s: SCAN family needs I == 1", fn);
+    if (res.status == TRL_ERR_UNSUPPORTED) res = seq();
+    if (res.status != 0) return fail(res.status, "%s: launch rejected (grid too large?)", fn);
+    if (int rc = check_launch(fn)) return rc;
+    g_kernel = res.kernel;
+    return TRL_OK;
+}
+
+extern "C" int trl_gae_bwd(void *stream, int val_dtype, int coef_dtype, const void *grad_advantage, const void *grad_value_target,
+                           const uint8_t *done, const uint8_t *terminated, int mask_bcast, const void *gamma_t, const void *lg_t,
+                           double gamma, double lmbda, double lg, int64_t O, int64_t T, int64_t I, void *d_reward,
+                           void *d_state_value, void *d_next_state_value, void *workspace, size_t workspace_bytes, int algo) {
+    if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_bwd: bad dtype");
+    if (int rc = check_dims("trl_gae_bwd", O, T, I)) return rc;
+    if (!done || !terminated || (!grad_advantage && !grad_value_target)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_bwd: null tensor pointer");
+    if (!d_reward && !d_state_value && !d_next_state_value) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_bwd: no output requested");
+    if (lg_t && !gamma_t) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_bwd: lg_t given without gamma_t");
+    GaeBwdArgs a{grad_advantage, grad_value_target, done, terminated, gamma_t, lg_t, gamma, lmbda, lg, O, T, I,
+                 d_reward, d_state_value, d_next_state_value, (mask_bcast && I > 1) ? 1 : 0};
+    hipStream_t s = (hipStream_t)stream;
+    size_t lb_bytes = 0;
+    void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
+    return bwd_dispatch("trl_gae_bwd", algo, [&] { return launch_gae_bwd_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes); },
+                        [&] { return launch_gae_bwd_seq(s, val_dtype, coef_dtype, a); });
+}
+
+static int td_bwd_impl(const char *fn, int td1, void *stream, int val_dtype, int coef_dtype, const void *grad_returns,
+                       const uint8_t *done, const uint8_t *terminated, int mask_bcast, const void *gamma_t, const void *lmbda_t,
+                       double gamma, double lmbda, int64_t O, int64_t T, int64_t I, void *d_reward, void *d_next_state_value,
+                       void *workspace, size_t workspace_bytes, int algo) {
+    if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "%s: bad dtype", fn);
+    if (int rc = check_dims(fn, O, T, I)) return rc;
+    if (!done || !terminated || !grad_returns) return fail(TRL_ERR_INVALID_ARGUMENT, "%s: null tensor pointer", fn);
+    if (!d_reward && !d_next_state_value) return fail(TRL_ERR_INVALID_ARGUMENT, "%s: no output requested", fn);
+    TdBwdArgs a{grad_returns, done, terminated, gamma_t, lmbda_t, gamma, lmbda, O, T, I, d_reward, d_next_state_value,
+                (mask_bcast && I > 1) ? 1 : 0};
+    hipStream_t s = (hipStream_t)stream;
+    size_t lb_bytes = 0;
+    void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
+    return bwd_dispatch(fn, algo, [&] { return launch_td_bwd_scan(s, val_dtype, coef_dtype, a, td1, lb, lb_bytes); },
+                        [&] { return launch_td_bwd_seq(s, val_dtype, coef_dtype, a, td1); });
+}
+
+extern "C" int trl_td_lambda_bwd(void *stream, int val_dtype, int coef_dtype, const void *grad_returns, const uint8_t *done,
+                                 const uint8_t *terminated, int mask_bcast, const void *gamma_t, const void *lmbda_t, double gamma,
+                                 double lmbda, int64_t O, int64_t T, int64_t I, void *d_reward, void *d_next_state_value,
+                                 void *workspace, size_t workspace_bytes, int algo) {
+    return td_bwd_impl("trl_td_lambda_bwd", 0, stream, val_dtype, coef_dtype, grad_returns, done, terminated, mask_bcast, gamma_t,
+                       lmbda_t, gamma, lmbda, O, T, I, d_reward, d_next_state_value, workspace, workspace_bytes, algo);
+}
+
+extern "C" int trl_td1_bwd(void *stream, int val_dtype, int coef_dtype, const void *grad_returns, const uint8_t *done,
+                           const uint8_t *terminated, int mask_bcast, const void *gamma_t, double gamma, int64_t O, int64_t T,
+                           int64_t I, void *d_reward, void *d_next_state_value, void *workspace, size_t workspace_bytes, int algo) {
+    return td_bwd_impl("trl_td1_bwd", 1, stream, val_dtype, coef_dtype, grad_returns, done, terminated, mask_bcast, gamma_t, nullptr,
+                       gamma, 1.0, O, T, I, d_reward, d_next_state_value, workspace, workspace_bytes, algo);
+}
+
+extern "C" int trl_vtrace_bwd(void *stream, int val_dtype, int coef_dtype, const void *grad_advantage, const void *grad_vs,
+                              const void *log_pi, const void *log_mu, const void *state_value, const void *next_state_value,
+                              const void *reward, const void *vs, const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                              const void *gamma_t, double gamma, double rho_thresh, double c_thresh, const void *rho_thresh_t,
+                              const void *c_thresh_t, int64_t O, int64_t T, int64_t I,
+                              void *d_log_pi, void *d_log_mu, void *d_state_value, void *d_next_state_value, void *d_reward,
+                              void *d_gamma_t, void *workspace, size_t workspace_bytes, int algo) {
+    if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_bwd: bad dtype");
+    if (int rc = check_dims("trl_vtrace_bwd", O, T, I)) return rc;
+    if (!log_pi || !log_mu || !state_value || !next_state_value || !reward || !vs || !done || !terminated ||
+        (!grad_advantage && !grad_vs))
+        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_bwd: null tensor pointer");
+    if (!d_log_pi && !d_log_mu && !d_state_value && !d_next_state_value && !d_reward && !d_gamma_t)
+        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_bwd: no output requested");
+    VtraceBwdArgs a{grad_advantage, grad_vs, log_pi, log_mu, state_value, next_state_value, reward, vs, done, terminated, gamma_t,
+                    gamma, rho_thresh, c_thresh, O, T, I, d_log_pi, d_log_mu, d_state_value, d_next_state_value, d_reward,
+                    d_gamma_t, (mask_bcast && I > 1) ? 1 : 0, rho_thresh_t, c_thresh_t};
+    hipStream_t s = (hipStream_t)stream;
+    size_t lb_bytes = 0;
+    void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
+    return bwd_dispatch("trl_vtrace_bwd", algo, [&] { return launch_vtrace_bwd_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes); },
+                        [&] { return launch_vtrace_bwd_seq(s, val_dtype, coef_dtype, a); });
+}
+
+
 extern "C" {
 
 int trl_abi_version(void) { return TRL_ABI_VERSION; }
@@ -223,10 +313,45 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype, const void *r
     return TRL_OK;
 }
 
+int trl_td1_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *next_state_value,
+                const uint8_t *done, const uint8_t *terminated, int mask_bcast, const void *gamma_t, double gamma,
+                int rolling_gamma, int64_t O, int64_t T, int64_t I, void *returns, void *workspace, size_t workspace_bytes,
+                int algo) {
+    if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td1_fwd: bad dtype");
+    if (int rc = check_dims("trl_td1_fwd", O, T, I)) return rc;
+    if (!reward || !next_state_value || !done || !terminated || !returns)
+        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td1_fwd: null tensor pointer");
+    if (!rolling_gamma && !gamma_t) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td1_fwd: rolling_gamma=0 needs a gamma tensor");
+    TdLambdaArgs a{reward, next_state_value, done, terminated, gamma_t, nullptr, gamma, 1.0, O, T, I, returns,
+                   (mask_bcast && I > 1) ? 1 : 0};
+    hipStream_t s = (hipStream_t)stream;
+    LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
+    if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ && algo != TRL_ALGO_LOCKSTEP)
+        return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td1_fwd: unknown algo %d", algo);
+    size_t lb_bytes = 0;
+    void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
+    if (rolling_gamma && algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I))
+        res = launch_td1_lockstep(s, val_dtype, coef_dtype, a);
+    if (res.status == TRL_ERR_UNSUPPORTED && rolling_gamma && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN))
+        res = launch_td1_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
+    if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
+        return fail(TRL_ERR_UNSUPPORTED, "trl_td1_fwd: SCAN family does not support this case (needs I == 1, rolling gamma)");
+    if (res.status == TRL_ERR_UNSUPPORTED && rolling_gamma && ((algo == TRL_ALGO_AUTO && lockstep_over_seq(O, I)) || algo == TRL_ALGO_LOCKSTEP))
+        res = launch_td1_lockstep(s, val_dtype, coef_dtype, a);
+    if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_LOCKSTEP)
+        return fail(TRL_ERR_UNSUPPORTED, "trl_td1_fwd: LOCKSTEP family needs 2 <= I <= 31, rolling gamma");
+    if (res.status == TRL_ERR_UNSUPPORTED) res = launch_td1_seq(s, val_dtype, coef_dtype, a, rolling_gamma);
+    if (res.status != 0) return fail(res.status, "trl_td1_fwd: launch rejected (grid too large?)");
+    if (int rc = check_launch("trl_td1_fwd")) return rc;
+    g_kernel = res.kernel;
+    return TRL_OK;
+}
+
 int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_pi, const void *log_mu,
                    const void *state_value, const void *next_state_value, const void *reward,
                    const uint8_t *done, const uint8_t *terminated, int mask_bcast, const void *gamma_t, double gamma,
-                   double rho_thresh, double c_thresh, int64_t O, int64_t T, int64_t I,
+                   double rho_thresh, double c_thresh, const void *rho_thresh_t, const void *c_thresh_t,
+                   int64_t O, int64_t T, int64_t I,
                    void *advantage, void *vs, void *workspace, size_t workspace_bytes, int algo) {
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_fwd: bad dtype");
     if (int rc = check_dims("trl_vtrace_fwd", O, T, I)) return rc;
@@ -234,11 +359,14 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_fwd: null tensor pointer");
     if (int rc = check_shifted("trl_vtrace_fwd", next_state_value, I, algo)) return rc;
     VtraceArgs a{log_pi, log_mu, state_value, next_state_value, reward, done, terminated, gamma_t,
-                 gamma, rho_thresh, c_thresh, O, T, I, advantage, vs, (mask_bcast && I > 1) ? 1 : 0};
+                 gamma, rho_thresh, c_thresh, O, T, I, advantage, vs, (mask_bcast && I > 1) ? 1 : 0, rho_thresh_t, c_thresh_t};
     hipStream_t s = (hipStream_t)stream;
     LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
     if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ && algo != TRL_ALGO_LOCKSTEP)
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_fwd: unknown algo %d", algo);
+    if ((rho_thresh_t || c_thresh_t) && algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SEQ)
+        return fail(TRL_ERR_UNSUPPORTED, "trl_vtrace_fwd: per-element clipping thresholds run on the SEQ family only");
+    if (rho_thresh_t || c_thresh_t) algo = TRL_ALGO_SEQ;
     size_t lb_bytes = 0;
     void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
     if (algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I)) res = launch_vtrace_lockstep(s, val_dtype, coef_dtype, a);

@@ -113,6 +113,43 @@ struct VtraceArgs {
     i64 O, T, I;
     void *advantage, *vs;
     int mask_bcast;
+    const void *rho_t = nullptr, *c_t = nullptr;  // optional per-element clipping thresholds (value dtype): SEQ family only
+};
+
+// ---- backward (adjoint) parameter blocks: bwd_kernels.hip ------------------------------------------------------
+// Optional pointers may be null: a null incoming gradient is a tensor of zeros, a null output is not written.
+struct GaeBwdArgs {
+    const void *g_adv, *g_vt;  // incoming gradients w.r.t. advantage / value_target (value dtype)
+    const u8 *done, *terminated;
+    const void *gamma_t, *lg_t;
+    double gamma, lmbda, lg;
+    i64 O, T, I;
+    void *d_reward, *d_value, *d_next_value;  // value dtype; d_reward is the adjoint G itself
+    int mask_bcast;
+};
+
+struct TdBwdArgs {  // TD(lambda) (rolling gamma) and TD(1) (lmbda unused)
+    const void *g_ret;
+    const u8 *done, *terminated;
+    const void *gamma_t, *lmbda_t;
+    double gamma, lmbda;
+    i64 O, T, I;
+    void *d_reward, *d_next_value;
+    int mask_bcast;
+};
+
+struct VtraceBwdArgs {
+    const void *g_adv, *g_vs;  // compute dtype (what trl_vtrace_fwd wrote)
+    const void *log_pi, *log_mu, *value, *next_value, *reward;
+    const void *vs;            // saved forward output (compute dtype)
+    const u8 *done, *terminated;
+    const void *gamma_t;
+    double gamma, rho_thresh, c_thresh;
+    i64 O, T, I;
+    void *d_log_pi, *d_log_mu, *d_value, *d_next_value, *d_reward;  // value dtype
+    void *d_gamma_t;                                                // compute dtype
+    int mask_bcast;
+    const void *rho_t = nullptr, *c_t = nullptr;  // optional per-element clipping thresholds (value dtype): SEQ family only
 };
 
 // Host-side launchers (defined in the .hip files, called from capi.hip).  Each returns the
@@ -122,6 +159,17 @@ struct LaunchResult { int status; i64 npartials; const char *kernel; };
 LaunchResult launch_gae_seq(hipStream_t s, int vdt, int cdt, const GaeArgs &a);
 LaunchResult launch_td_lambda_seq(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, int rolling);
 LaunchResult launch_vtrace_seq(hipStream_t s, int vdt, int cdt, const VtraceArgs &a);
+// TD(1): TdLambdaArgs with lmbda unused
+LaunchResult launch_td1_seq(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, int rolling);
+LaunchResult launch_td1_scan(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, void *lb_ws, size_t lb_bytes);
+LaunchResult launch_td1_lockstep(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a);
+// adjoints (bwd_kernels.hip): SCAN family for I == 1 (status 2 otherwise), SEQ for every shape
+LaunchResult launch_gae_bwd_scan(hipStream_t s, int vdt, int cdt, const GaeBwdArgs &a, void *lb_ws, size_t lb_bytes);
+LaunchResult launch_gae_bwd_seq(hipStream_t s, int vdt, int cdt, const GaeBwdArgs &a);
+LaunchResult launch_td_bwd_scan(hipStream_t s, int vdt, int cdt, const TdBwdArgs &a, int td1, void *lb_ws, size_t lb_bytes);
+LaunchResult launch_td_bwd_seq(hipStream_t s, int vdt, int cdt, const TdBwdArgs &a, int td1);
+LaunchResult launch_vtrace_bwd_scan(hipStream_t s, int vdt, int cdt, const VtraceBwdArgs &a, void *lb_ws, size_t lb_bytes);
+LaunchResult launch_vtrace_bwd_seq(hipStream_t s, int vdt, int cdt, const VtraceBwdArgs &a);
 
 // lb_ws / lb_bytes: optional look-back region of the workspace (scan_lookback_bytes), else nullptr / 0
 LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a, void *lb_ws, size_t lb_bytes);

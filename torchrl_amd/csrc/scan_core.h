@@ -110,6 +110,40 @@ __device__ __forceinline__ void store_n(T *__restrict__ p, i64 flat, int nvalid,
         if (e < nvalid) p[flat + e] = in[e];
 }
 
+// Reversed addressing (adjoint ops): the lane's element e of the REVERSED flat order, flat + e, sits at memory index
+// n_total - 1 - (flat + e).  A lane's V elements are still one contiguous, naturally aligned vector (n_total % V == 0
+// is the launcher's condition for VEC), read once and turned around in registers; a wave still touches 64*V
+// consecutive elements per instruction.
+template <bool VEC, typename T, int V>
+__device__ __forceinline__ void load_n_rev(const T *__restrict__ p, i64 n_total, i64 flat, int nvalid, T (&out)[V]) {
+    if constexpr (VEC) {
+        if (nvalid == V) {
+            T tmp[V];
+            vload<T, V>(p + (n_total - flat - V), tmp);
+#pragma unroll
+            for (int e = 0; e < V; ++e) out[e] = tmp[V - 1 - e];
+            return;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) out[e] = e < nvalid ? p[n_total - 1 - flat - e] : (T)0;
+}
+template <bool VEC, typename T, int V>
+__device__ __forceinline__ void store_n_rev(T *__restrict__ p, i64 n_total, i64 flat, int nvalid, const T (&in)[V]) {
+    if constexpr (VEC) {
+        if (nvalid == V) {
+            T tmp[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) tmp[e] = in[V - 1 - e];
+            vstore<T, V>(p + (n_total - flat - V), tmp);
+            return;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+        if (e < nvalid) p[n_total - 1 - flat - e] = in[e];
+}
+
 template <typename T>
 __device__ __forceinline__ T clamp_max_nan(T x, T hi) { return (x != x) ? x : (x > hi ? hi : x); }
 __device__ __forceinline__ float exp_t(float x) { return expf(x); }
@@ -181,6 +215,8 @@ struct GaeOp {
     static constexpr int V = V_;
     static constexpr bool kNeedsNext = false;
     static constexpr bool kShifted = false;  // see Shifted<> below
+    static constexpr bool kReversed = false;    // see the adjoint ops (bwd_ops.h)
+    static constexpr bool kCustomEmit = false;
     struct Raw {
         TS r[V], v[V], nv[V];
         u8 d[V], tm[V];
@@ -264,6 +300,8 @@ struct TdLambdaOp {
     static constexpr int V = V_;
     static constexpr bool kNeedsNext = false;
     static constexpr bool kShifted = false;
+    static constexpr bool kReversed = false;
+    static constexpr bool kCustomEmit = false;
     struct Raw {
         TS r[V], nv[V];
         u8 d[V], tm[V];
@@ -322,6 +360,72 @@ struct TdLambdaOp {
     }
 };
 
+// TD(1) return, rolling gamma (functional.py:515-549): g starts from the RAW next value of the row's last step,
+//   g = r + (gamma*nt) * ((1 - dnt)*g + dnt*v'),  dnt = done & ~terminated.
+// Same tensors as TD(lambda) (TdLambdaArgs; lmbda unused).
+template <typename TS_, typename TG_, int V_>
+struct Td1Op {
+    typedef TS_ TS;
+    typedef TG_ TG;
+    typedef typename Promote<TS, TG>::type TC;
+    typedef TdLambdaArgs Args;
+    static constexpr int V = V_;
+    static constexpr bool kNeedsNext = false;
+    static constexpr bool kShifted = false;
+    static constexpr bool kReversed = false;
+    static constexpr bool kCustomEmit = false;
+    struct Raw {
+        TS r[V], nv[V];
+        u8 d[V], tm[V];
+        TG g[V];
+    };
+    TS r[V], nv[V], dnt[V], omdnt[V];
+    TG gnt[V];
+
+    typedef TS TO;
+    static constexpr int kNumOut = 1;
+    static __device__ __forceinline__ TO *out_ptr(const Args &a, int) { return (TO *)a.returns; }
+    template <class F>
+    static __device__ __forceinline__ void for_each_input(const Args &a, Raw &w, F &&f) {
+        f((const TS *)a.reward, w.r);
+        f((const TS *)a.next_value, w.nv);
+        f(a.done, w.d);
+        f(a.terminated, w.tm);
+        f((const TG *)a.gamma_t, w.g);   // optional
+    }
+    __device__ __forceinline__ void prepare(const Args &a, const Raw &w) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            r[e] = w.r[e];
+            nv[e] = w.nv[e];
+            gnt[e] = (a.gamma_t ? w.g[e] : (TG)a.gamma) * (TG)(w.tm[e] ? 0 : 1);
+            const bool b = w.d[e] && !w.tm[e];
+            dnt[e] = (TS)(b ? 1 : 0);
+            omdnt[e] = (TS)(b ? 0 : 1);
+        }
+    }
+    __device__ __forceinline__ TC init(int e) const { return (TC)nv[e]; }
+    __device__ __forceinline__ TC step(int e, TC x) const {
+        return (TC)r[e] + (TC)gnt[e] * ((TC)omdnt[e] * x + (TC)(dnt[e] * nv[e]));
+    }
+    __device__ __forceinline__ void affine(int e, TC &a, TC &b) const {
+        a = (TC)gnt[e] * (TC)omdnt[e];
+        b = (TC)r[e] + (TC)gnt[e] * (TC)(dnt[e] * nv[e]);
+    }
+    __device__ __forceinline__ TS first_value() const { return (TS)0; }
+    __device__ __forceinline__ void outputs(int, const TC (&x)[V], const bool (&)[V], TC, TS, TO (&o0)[V], TO (&)[V],
+                                            double &, double &) const {
+#pragma unroll
+        for (int e = 0; e < V; ++e) o0[e] = (TS)x[e];
+    }
+    __device__ __forceinline__ TS value(int) const { return (TS)0; }
+    __device__ __forceinline__ void outputs_ls(bool, const TC (&x)[V], bool, const TC (&)[V], const TS (&)[V], TO (&o0)[V],
+                                               TO (&)[V], double &, double &) const {
+#pragma unroll
+        for (int e = 0; e < V; ++e) o0[e] = (TS)x[e];
+    }
+};
+
 template <typename TS_, typename TG_, int V_>
 struct VtraceOp {
     typedef TS_ TS;
@@ -331,6 +435,8 @@ struct VtraceOp {
     static constexpr int V = V_;
     static constexpr bool kNeedsNext = true;
     static constexpr bool kShifted = false;
+    static constexpr bool kReversed = false;
+    static constexpr bool kCustomEmit = false;
     struct Raw {
         TS lp[V], lmu[V], v[V], nv[V], r[V];
         u8 d[V], tm[V];
@@ -429,6 +535,14 @@ using VtraceShiftedOp = Shifted<VtraceOp<TS, TG, V>>;
 // ---- generic load / store over an Op's tensor lists ------------------------------------------------
 template <class Op, bool VEC>
 __device__ __forceinline__ void load_inputs(const typename Op::Args &a, i64 flat, int nvalid, typename Op::Raw &w) {
+    if constexpr (Op::kReversed) {
+        const i64 n_total = a.O * a.T;  // reversed ops are I == 1 only
+        Op::for_each_input(a, w, [&](auto *base, auto &dst) {
+            if (base) load_n_rev<VEC>(base, n_total, flat, nvalid, dst);
+        });
+        Op::load_extra(a, n_total, flat, nvalid, w);
+        return;
+    }
     if constexpr (Op::kShifted) {
         Op::for_each_unshifted_input(a, w, [&](auto *base, auto &dst) {
             if (base) load_n<VEC>(base, flat, nvalid, dst);
@@ -445,6 +559,20 @@ __device__ __forceinline__ void store_outputs(const typename Op::Args &a, i64 fl
                                               const typename Op::TO (&o0)[Op::V], const typename Op::TO (&o1)[Op::V]) {
     store_n<VEC>(Op::out_ptr(a, 0), flat, nvalid, o0);
     if (Op::kNumOut > 1) store_n<VEC>(Op::out_ptr(a, 1), flat, nvalid, o1);
+}
+
+// epilogue of a lane's V steps: the estimator's outputs, stored (adjoint ops write their own, reversed, set)
+template <class Op, bool VEC>
+__device__ __forceinline__ void emit_outputs(const Op &op, const typename Op::Args &a, i64 flat, int nvalid,
+                                             const typename Op::TC (&xs)[Op::V], const bool (&row_end)[Op::V],
+                                             typename Op::TC x_in, typename Op::TS v_next, double &s, double &ss) {
+    if constexpr (Op::kCustomEmit) {
+        op.template emit<VEC>(a, flat, nvalid, xs, row_end, x_in, v_next);
+    } else {
+        typename Op::TO o0[Op::V], o1[Op::V];
+        op.outputs(nvalid, xs, row_end, x_in, v_next, o0, o1, s, ss);
+        store_outputs<Op, VEC>(a, flat, nvalid, o0, o1);
+    }
 }
 
 // ---- scan of one chunk by one team (kWaves waves) ---------------------------------------------

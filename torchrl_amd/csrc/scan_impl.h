@@ -1,0 +1,651 @@
+// Wavefront-scan kernels ("SCAN" family): kernel templates, plan and launcher, shared by scan_kernels.hip (forward
+// estimators) and bwd_kernels.hip (their adjoints).  Time-contiguous rows (I == 1) unless noted.
+//
+// The recurrence x_t = b_t + a_t * x_{t+1} (GAE: a = lmbda*gamma*(1-done), b = delta;
+// TD(lambda): a = gamma*lmbda*(1-done), b = r + gamma*v'*(1 - lmbda*(1-done)); V-trace:
+// a = gamma*(1-done)*c, b = rho*delta) is a reverse scan of affine maps (a, b).  The flat
+// (O*T) array is cut into chunks of kWaves*64*V consecutive elements:
+//   1. every lane loads V consecutive time steps with one 16-byte load per tensor
+//      (fully coalesced: a wave reads 1 KiB per instruction), fuses the delta / coefficient
+//      computation and composes its V maps in registers;
+//   2. the 64 lane aggregates are suffix-scanned with wave shuffles (6 steps);
+//   3. the wave aggregates of a chunk are exchanged through LDS (one barrier per chunk);
+//   4. every lane re-runs its V steps from its carry-in with the reference's exact
+//      per-step expression and writes its outputs with 16-byte stores.
+// Row ends are *hard* segment boundaries (the carry is discarded by a select, never
+// multiplied), `done` boundaries are soft zeros exactly as in the reference
+// (x*0, functional.py:174-178), so at a done step the result is delta_t bit-for-bit.
+//
+// Two geometries, no inter-block communication in either:
+//   SHORT rows (T <= chunk): a chunk is R whole rows (R*T <= chunk) and needs no carry.  The
+//                            kernel is persistent: ~one block of 4 teams (1024 threads) per CU,
+//                            each team walks chunks grid-stride with the next chunk's loads
+//                            issued before the current one is scanned, so reads and writes of
+//                            neighbouring chunks overlap in time.
+//   LONG rows  (T >  chunk): a block (one team) owns whole rows and walks each row's chunks from
+//                            the end, carrying x (and V-trace's vs) in registers, again with the
+//                            next chunk prefetched.
+//
+// HBM traffic = algorithmic bytes: each input element is read once, each output written
+// once (GAE fp32 22 B / transition); per-block {sum, sumsq} partials add 16 B per block.
+#pragma once
+#include <type_traits>
+
+#include "scan_core.h"
+
+namespace {
+
+using namespace scan;
+constexpr int kTeams = 4;                       // SHORT geometry: teams per block
+constexpr int kShortThreads = kTeams * kTeam;   // 1024
+constexpr int kLongThreads = kTeam;             // 256
+
+struct ScanGeom {
+    i64 O, T;
+    int rows_per_chunk;  // SHORT geometry
+    int scan_lanes;      // bound on the lanes one row spans (shuffle steps)
+    i64 nchunks;         // SHORT geometry
+};
+
+__device__ __forceinline__ int clamp_nvalid(int count, int lane_off, int V) {
+    const int nv = count - lane_off;
+    return nv < 0 ? 0 : (nv > V ? V : nv);
+}
+
+// ---- SHORT rows: persistent, 4 teams per block -------------------------------------------------
+template <class Op, bool VEC, bool WAVE_INDEP>
+__global__ __launch_bounds__(kShortThreads) void scan_short_kernel(typename Op::Args args, ScanGeom geo, double *partials) {
+    typedef typename Op::TC TC;
+    typedef typename Op::TS TS;
+    constexpr int V = Op::V;
+    constexpr int NW = kShortThreads / kWave;
+    __shared__ TeamShared<Op> sh[kTeams];
+    __shared__ double red[2 * NW];
+    const int team = threadIdx.x / kTeam;
+    const int lane_off = (threadIdx.x & (kTeam - 1)) * V;
+    const unsigned T = (unsigned)geo.T;
+    const i64 stride = (i64)gridDim.x * kTeams;
+    const i64 niter = (geo.nchunks + stride - 1) / stride;  // uniform over the grid (barriers inside scan_chunk)
+
+    auto geom_of = [&](i64 it, i64 &start, int &count) {
+        const i64 c = it * stride + (i64)blockIdx.x * kTeams + team;
+        const i64 row0 = c * geo.rows_per_chunk;
+        i64 nrows = c < geo.nchunks ? geo.O - row0 : 0;
+        if (nrows > geo.rows_per_chunk) nrows = geo.rows_per_chunk;
+        if (nrows < 0) nrows = 0;
+        start = row0 * geo.T;
+        count = (int)(nrows * geo.T);
+    };
+
+    double s = 0.0, ss = 0.0;
+    typename Op::Raw cur, nxt;
+    i64 start;
+    int count;
+    geom_of(0, start, count);
+    load_inputs<Op, VEC>(args, start + lane_off, clamp_nvalid(count, lane_off, V), cur);
+    for (i64 it = 0; it < niter; ++it) {
+        if (it + 1 < niter) {
+            i64 nstart;
+            int ncount;
+            geom_of(it + 1, nstart, ncount);
+            load_inputs<Op, VEC>(args, nstart + lane_off, clamp_nvalid(ncount, lane_off, V), nxt);
+        }
+        geom_of(it, start, count);
+        const int nvalid = clamp_nvalid(count, lane_off, V);
+        const i64 flat = start + lane_off;
+        Op op;
+        op.prepare(args, cur);
+        TC Xc = (TC)0;
+        TS Xv = (TS)0;
+        scan_chunk<Op, WAVE_INDEP>(op, sh[team], (int)(it & 1), nvalid, (unsigned)lane_off % T, T, geo.scan_lanes, Xc, Xv,
+                                   [&](const TC(&xs)[V], const bool(&row_end)[V], TC x_in, TS v_next) {
+                                       emit_outputs<Op, VEC>(op, args, flat, nvalid, xs, row_end, x_in, v_next, s, ss);
+                                   });
+        cur = nxt;
+    }
+    if (partials) {
+        block_sum2<kShortThreads>(s, ss, red);
+        if (threadIdx.x == 0) {
+            partials[2 * (i64)blockIdx.x] = s;
+            partials[2 * (i64)blockIdx.x + 1] = ss;
+        }
+    }
+}
+
+
+// ---- SHORT rows with feature dims (I > 1, T*I <= chunk) -------------------------------------------
+// Element (o, t, i) sits at (o*T + t)*I + i: the I scans of one outer row are interleaved in
+// memory.  A team takes a chunk of RO whole outer rows (one contiguous byte range per tensor),
+// loads it with the same coalesced 16-byte loads as the I == 1 kernels, and transposes it through
+// LDS so that every lane ends up holding V consecutive time steps of ONE (o, i) row: the chunk
+// then looks exactly like RO*I time-contiguous rows of length T and goes through the same
+// scan_chunk.  Outputs take the inverse route (LDS scatter, coalesced 16-byte stores), so HBM
+// traffic stays at the algorithmic bytes.
+#ifndef IL_WAVES
+#define IL_WAVES 4
+#endif
+template <class Op, bool VEC, bool WAVE_INDEP, bool PAD>
+__global__ __launch_bounds__(kTeam, IL_WAVES) void scan_interleaved_kernel(typename Op::Args args, ScanGeom geo, int I, double *partials) {
+    typedef typename Op::TC TC;
+    typedef typename Op::TS TS;
+    typedef typename Op::TO TO;
+    constexpr int V = Op::V;
+    constexpr int CH = kTeam * V;
+    // The gather / scatter by (o, i) row walks the LDS arrays with a stride of V*I elements between lanes.  When that is a
+    // multiple of 8 words a row's lanes fold onto 4, 2 or 1 of the 32 banks ([8192x128x8] 90 us): the arrays then carry 4
+    // pad elements per 128 (index p -> p + 4 * (p / 128)), which spreads the lanes again and keeps the staging's 16-byte
+    // LDS accesses aligned (34 us; one pad element per 32 was conflict-free but made the staging scalar: 40 us).
+    constexpr int CHP = CH + CH / 32;
+    constexpr bool padded = PAD;  // chosen by the launcher (launch_scan)
+    auto pad = [&](int p) { return padded ? p + ((p >> 7) << 2) : p; };
+    __shared__ __align__(16) unsigned char lds_in[sizeof(typename Op::Raw) * kTeam / 32 * 33];
+    __shared__ __align__(16) TO lds_out[Op::kNumOut][CHP];
+    __shared__ TeamShared<Op> sh;
+    __shared__ double red[2 * kWaves];
+    const int lane_off = (int)threadIdx.x * V;
+    const unsigned T = (unsigned)geo.T;
+    const i64 row_elems = geo.T * I;  // elements of one outer row
+
+    // virtual (row-major per (o,i)) position of this lane's first element inside a chunk, and the
+    // physical in-chunk offset of each of its V elements
+    int pe[V], pm[V];  // pm: offset of the step's mask byte when the masks are shared by the I feature elements
+    {
+        unsigned rv = (unsigned)lane_off / T, t = (unsigned)lane_off % T;
+        unsigned ol = rv / (unsigned)I, i = rv % (unsigned)I;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            pe[e] = pad((int)((ol * T + t) * (unsigned)I + i));
+            pm[e] = pad((int)(ol * T + t));
+            if (++t == T) { t = 0; if (++i == (unsigned)I) { i = 0; ++ol; } }
+        }
+    }
+    const unsigned t0 = (unsigned)lane_off % T;
+    const bool bcast = args.mask_bcast != 0;
+    const bool mvec = VEC && ((geo.rows_per_chunk * geo.T) % 4 == 0);  // mask chunk starts stay dword-aligned
+
+    auto geom_of = [&](i64 c, i64 &start, int &count) {
+        const i64 row0 = c * geo.rows_per_chunk;
+        i64 nrows = c < geo.nchunks ? geo.O - row0 : 0;
+        if (nrows > geo.rows_per_chunk) nrows = geo.rows_per_chunk;
+        if (nrows < 0) nrows = 0;
+        start = row0 * row_elems;
+        count = (int)(nrows * row_elems);
+    };
+
+    double s = 0.0, ss = 0.0;
+    i64 start;
+    int count;
+    // No register prefetch here: the kernel is occupancy-bound (VGPRs), and with up to 8 teams per
+    // CU in flight the other teams' loads cover this team's latency.
+    const i64 niter = (geo.nchunks + gridDim.x - 1) / gridDim.x;
+    for (i64 it = 0; it < niter; ++it) {
+        const i64 c = it * gridDim.x + blockIdx.x;
+        geom_of(c, start, count);
+        const int nvalid = clamp_nvalid(count, lane_off, V);
+        typename Op::Raw cur;
+        Op::for_each_input(args, cur, [&](auto *base, auto &arr) {
+            typedef typename std::remove_reference<decltype(arr[0])>::type E;
+            if (!base) return;
+            if (sizeof(E) == 1 && bcast) {  // (count / I) mask bytes, one per step of the chunk's outer rows
+                const i64 mstart = c * geo.rows_per_chunk * geo.T;  // = start / I without the division
+                const int mvalid = clamp_nvalid((int)(count == (int)(geo.rows_per_chunk * row_elems) ? geo.rows_per_chunk * geo.T : count / I), lane_off, V);
+                if (mvec) load_n<true>(base, mstart + lane_off, mvalid, arr);
+                else load_n<false>(base, mstart + lane_off, mvalid, arr);
+            } else {
+                load_n<VEC>(base, start + lane_off, nvalid, arr);
+            }
+        });
+        // stage the chunk in LDS in memory order, then gather this lane's (o,i)-row elements
+        {
+            size_t off = 0;
+            Op::for_each_input(args, cur, [&](auto *base, auto &arr) {
+                typedef typename std::remove_reference<decltype(arr[0])>::type E;
+                if (base) {
+                    if (padded) {  // a lane's V elements share a group: contiguous and still aligned
+                        E *dst = (E *)__builtin_assume_aligned((E *)(lds_in + off) + pad(lane_off), V * sizeof(E) <= 16 ? V * sizeof(E) : 16);
+#pragma unroll
+                        for (int e = 0; e < V; ++e) dst[e] = arr[e];
+                    } else {
+                        E *dst = (E *)(lds_in + off) + lane_off;
+#pragma unroll
+                        for (int e = 0; e < V; ++e) dst[e] = arr[e];
+                    }
+                }
+                off += sizeof(E) * CHP;
+            });
+        }
+        __syncthreads();
+        typename Op::Raw vraw;
+        {
+            size_t off = 0;
+            Op::for_each_input(args, vraw, [&](auto *base, auto &arr) {
+                typedef typename std::remove_reference<decltype(arr[0])>::type E;
+                if (base) {
+                    const E *src = (const E *)(lds_in + off);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) arr[e] = e < nvalid ? src[(sizeof(E) == 1 && bcast) ? pm[e] : pe[e]] : (E)0;
+                }
+                off += sizeof(E) * CHP;
+            });
+        }
+        Op op;
+        op.prepare(args, vraw);
+        TC Xc = (TC)0;
+        TS Xv = (TS)0;
+        scan_chunk<Op, WAVE_INDEP>(op, sh, (int)(it & 1), nvalid, t0, T, geo.scan_lanes, Xc, Xv,
+                                   [&](const TC(&xs)[V], const bool(&row_end)[V], TC x_in, TS v_next) {
+                                       TO o0[V], o1[V];
+                                       op.outputs(nvalid, xs, row_end, x_in, v_next, o0, o1, s, ss);
+#pragma unroll
+                                       for (int e = 0; e < V; ++e) {
+                                           if (e < nvalid) {
+                                               lds_out[0][pe[e]] = o0[e];
+                                               if (Op::kNumOut > 1) lds_out[Op::kNumOut - 1][pe[e]] = o1[e];
+                                           }
+                                       }
+                                   });
+        __syncthreads();
+        {
+            TO o0[V], o1[V];
+            if (padded) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    o0[e] = lds_out[0][pad(lane_off) + e];
+                    o1[e] = lds_out[Op::kNumOut - 1][pad(lane_off) + e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    o0[e] = lds_out[0][lane_off + e];
+                    o1[e] = lds_out[Op::kNumOut - 1][lane_off + e];
+                }
+            }
+            store_outputs<Op, VEC>(args, start + lane_off, nvalid, o0, o1);
+        }
+    }
+    if (partials) {
+        block_sum2<kTeam>(s, ss, red);
+        if (threadIdx.x == 0) {
+            partials[2 * (i64)blockIdx.x] = s;
+            partials[2 * (i64)blockIdx.x + 1] = ss;
+        }
+    }
+}
+
+// ---- LONG rows: one team per block walks (row, chunk) pairs from each row's end -----------------
+template <class Op, bool VEC>
+__global__ __launch_bounds__(kLongThreads) void scan_long_kernel(typename Op::Args args, ScanGeom geo, double *partials) {
+    typedef typename Op::TC TC;
+    typedef typename Op::TS TS;
+    constexpr int V = Op::V;
+    constexpr int kChunk = kLongThreads * V;
+    __shared__ TeamShared<Op> sh;
+    __shared__ double red[2 * kWaves];
+    double s = 0.0, ss = 0.0;
+    const unsigned T = (unsigned)geo.T;
+    const int lane_off = (int)threadIdx.x * V;
+    const int nchunks = (int)((geo.T + kChunk - 1) / kChunk);
+    auto chunk_count = [&](int cc) {
+        i64 cnt = geo.T - (i64)cc * kChunk;
+        return (int)(cnt > kChunk ? kChunk : cnt);
+    };
+    int buf = 0;
+    i64 row = blockIdx.x;
+    int c = nchunks - 1;
+    typename Op::Raw cur, nxt;
+    if (row < geo.O)
+        load_inputs<Op, VEC>(args, row * geo.T + (i64)c * kChunk + lane_off, clamp_nvalid(chunk_count(c), lane_off, V), cur);
+    TC Xc = (TC)0;
+    TS Xv = (TS)0;
+    while (row < geo.O) {
+        i64 nrow = row;
+        int nc = c - 1;
+        if (nc < 0) { nrow = row + gridDim.x; nc = nchunks - 1; }
+        if (nrow < geo.O)
+            load_inputs<Op, VEC>(args, nrow * geo.T + (i64)nc * kChunk + lane_off,
+                                   clamp_nvalid(chunk_count(nc), lane_off, V), nxt);
+        const i64 start = row * geo.T + (i64)c * kChunk;
+        const int nvalid = clamp_nvalid(chunk_count(c), lane_off, V);
+        const i64 flat = start + lane_off;
+        Op op;
+        op.prepare(args, cur);
+        scan_chunk<Op, false>(op, sh, buf, nvalid, (unsigned)((i64)c * kChunk + lane_off), T, kWave, Xc, Xv,
+                              [&](const TC(&xs)[V], const bool(&row_end)[V], TC x_in, TS v_next) {
+                                  emit_outputs<Op, VEC>(op, args, flat, nvalid, xs, row_end, x_in, v_next, s, ss);
+                              });
+        buf ^= 1;
+        cur = nxt;
+        row = nrow;
+        c = nc;
+    }
+    if (partials) {
+        block_sum2<kLongThreads>(s, ss, red);
+        if (threadIdx.x == 0) {
+            partials[2 * (i64)blockIdx.x] = s;
+            partials[2 * (i64)blockIdx.x + 1] = ss;
+        }
+    }
+}
+
+
+// ---- LONG rows, few of them: one chunk (4 teams) per block, decoupled look-back between chunks -------
+// When there are too few rows to fill the chip (O < ~2 * #CUs) a row's chunks are scanned in PARALLEL:
+// every block takes one chunk, publishes the chunk's aggregate map, then resolves its carry by
+// walking the records of the chunks that follow it in time ("look-back", here toward later time
+// because the scan runs from T-1 to 0) until it meets one whose inclusive value is known, and
+// publishes its own inclusive value.  Chunks are handed out through an atomic ticket in reverse
+// time order, so every chunk a block may wait on belongs to a block that has already started and
+// publishes its aggregate without waiting on anyone: progress is guaranteed for any dispatch order
+// or XCD placement.  Records are {flag | payload}: the payload is written with agent-scope
+// (write-through) stores, drained (s_waitcnt vmcnt(0)), then the flag is stored; the consumer polls
+// the flag with agent-scope loads and reads the payload with agent-scope loads
+// (MI355X_MICROARCH.md, valid hand-off forms).  Ticket and records are zeroed by a memset node on the
+// same stream before every launch.  Spins are bounded (1 s): on timeout NaNs are written.
+struct LbRecord {             // one 64-byte line per chunk; a field is never rewritten once its flag is up
+    unsigned long long flag;  // 0 none, 1 aggregate {a, b} valid, 2 inclusive {x} valid too
+    unsigned long long a, b;  // aggregate map of the chunk (double bits)
+    unsigned long long x;     // inclusive value: x of the chunk's first step
+    unsigned long long v0;    // V-trace: state_value of the chunk's first step
+    unsigned long long pad[3];
+};
+static_assert(sizeof(LbRecord) == 64, "record size");
+constexpr int kLbMaxRows = 512;
+struct LbHeader {
+    unsigned error;
+    unsigned pad[63];
+    struct { unsigned next; unsigned pad[15]; } row[kLbMaxRows];  // one ticket counter per row, each on its own 64-byte line
+};
+
+template <typename T>
+__device__ __forceinline__ unsigned long long lb_bits(T x) { return (unsigned long long)__double_as_longlong((double)x); }
+template <typename T>
+__device__ __forceinline__ T lb_val(unsigned long long b) { return (T)__longlong_as_double((long long)b); }
+__device__ __forceinline__ void lb_store(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long lb_load(const unsigned long long *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr int kLbTeams = 4;  // teams per look-back block: one ticket / one record per 4 * 256 * V steps
+
+template <class Op, bool VEC>
+__global__ __launch_bounds__(kLbTeams * kTeam) void scan_lookback_kernel(typename Op::Args args, ScanGeom geo, LbHeader *hdr,
+                                                                        LbRecord *rec) {
+    typedef typename Op::TC TC;
+    typedef typename Op::TS TS;
+    constexpr int V = Op::V;
+    constexpr int kChunk = kTeam * V;            // steps per team
+    constexpr int kBlk = kLbTeams * kChunk;      // steps per block = per ticket = per record
+    __shared__ TeamShared<Op> sh[kLbTeams];
+    __shared__ unsigned s_ticket;
+    __shared__ TC s_xc[kLbTeams];
+    __shared__ TS s_xv[kLbTeams];
+    const unsigned T = (unsigned)geo.T;
+    const int team = threadIdx.x / kTeam;
+    const int lane_off = (int)(threadIdx.x & (kTeam - 1)) * V;
+    const int nchunks = (int)((geo.T + kBlk - 1) / kBlk);
+
+    // One ticket per block, drawn from its ROW's counter (blocks are dealt to rows round-robin, so the rows'
+    // counters are hit in parallel): atomics on one address serialise (~13 ns each, measured), so they -- not
+    // HBM -- bound the kernel unless a ticket covers enough bytes.
+    const i64 row = blockIdx.x % geo.O;
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&hdr->row[row].next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int c = nchunks - 1 - (int)s_ticket;  // later chunks of a row draw earlier tickets
+    if (c < 0) return;
+    const i64 t_team = (i64)c * kBlk + (i64)team * kChunk;  // time index of the team's first step
+    i64 cnt = geo.T - t_team;
+    if (cnt > kChunk) cnt = kChunk;
+    if (cnt < 0) cnt = 0;
+    const int nvalid = clamp_nvalid((int)cnt, lane_off, V);
+    const i64 flat = row * geo.T + t_team + lane_off;
+    LbRecord *myrec = rec + row * nchunks + c;
+
+    typename Op::Raw raw;
+    load_inputs<Op, VEC>(args, flat, nvalid, raw);
+    Op op;
+    op.prepare(args, raw);
+    TC Xc = (TC)0;
+    TS Xv = (TS)0;
+    double s = 0.0, ss = 0.0;
+    scan_chunk<Op, false>(
+        op, sh[team], 0, nvalid, (unsigned)(t_team + lane_off), T, kWave, Xc, Xv,
+        [&](const TC(&xs)[V], const bool(&row_end)[V], TC x_in, TS v_next) {
+            emit_outputs<Op, VEC>(op, args, flat, nvalid, xs, row_end, x_in, v_next, s, ss);
+        },
+        [&](TeamShared<Op> &, int buf, TC &xc, TS &xv) {
+            // every team's wave aggregates are in LDS (scan_chunk's barrier is block-wide)
+            if (threadIdx.x < kWave) {  // wave 0 resolves the carries: 64 records per look-back round
+                const int lane = threadIdx.x;
+                Aff<TC> tagg[kLbTeams];  // team aggregates: x_first(team) = G0(G1(G2(G3(x_in))))
+#pragma unroll
+                for (int tm = 0; tm < kLbTeams; ++tm) {
+                    Aff<TC> g{sh[tm].a[buf][kWaves - 1], sh[tm].b[buf][kWaves - 1], sh[tm].h[buf][kWaves - 1]};
+#pragma unroll
+                    for (int w = kWaves - 2; w >= 0; --w) g = compose(Aff<TC>{sh[tm].a[buf][w], sh[tm].b[buf][w], sh[tm].h[buf][w]}, g);
+                    tagg[tm] = g;
+                }
+                Aff<TC> agg = tagg[kLbTeams - 1];
+#pragma unroll
+                for (int tm = kLbTeams - 2; tm >= 0; --tm) agg = compose(tagg[tm], agg);
+                const TS my_v0 = Op::kNeedsNext ? sh[0].v0[buf][0] : (TS)0;
+                TC carry = (TC)0;
+                TS carry_v = (TS)0;
+                bool ok = true;
+                if (agg.h) {
+                    // the block holds its row's end: inclusive value known at once
+                    if (lane == 0) {
+                        lb_store(&myrec->x, lb_bits(agg.b));
+                        lb_store(&myrec->v0, lb_bits(my_v0));
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        lb_store(&myrec->flag, 2ull);
+                    }
+                } else {
+                    if (lane == 0) {
+                        lb_store(&myrec->a, lb_bits(agg.a));
+                        lb_store(&myrec->b, lb_bits(agg.b));
+                        lb_store(&myrec->v0, lb_bits(my_v0));
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        lb_store(&myrec->flag, 1ull);
+                    }
+                    // look back: lane l reads the record of chunk base + l; the records up to the first inclusive
+                    // one are composed in chunk order by a wave reduction; no inclusive among the 64 -> next 64
+                    Aff<TC> acc{(TC)1, (TC)0, 0};
+                    const unsigned long long t_start = wall_clock64();
+                    for (int base = c + 1; ok; base += kWave) {
+                        const int idx = base + lane;
+                        const bool valid = idx < nchunks;
+                        const LbRecord *r = rec + row * nchunks + (valid ? idx : nchunks - 1);
+                        unsigned long long f = 0ull;
+                        int first = kWave;
+                        for (;;) {
+                            if (valid && f == 0ull) f = lb_load(&r->flag);  // only the records still missing are re-polled
+                            const unsigned long long incl = __ballot(valid && f == 2ull);
+                            first = incl ? (int)__ffsll((long long)incl) - 1 : kWave;
+                            if (__all(!(valid && lane <= first) || f != 0ull)) break;
+                            if (wall_clock64() - t_start > 100000000ull) { ok = false; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        if (!ok) break;
+                        if (first == kWave && !__all(valid)) { ok = false; break; }  // ran past the row's end: cannot happen
+                        Aff<TC> el{(TC)1, (TC)0, 0};
+                        if (valid && lane < first) el = Aff<TC>{lb_val<TC>(lb_load(&r->a)), lb_val<TC>(lb_load(&r->b)), 0};
+                        else if (valid && lane == first) el = Aff<TC>{(TC)0, lb_val<TC>(lb_load(&r->x)), 1};  // constant map
+                        if (base == c + 1 && lane == 0) carry_v = lb_val<TS>(lb_load(&r->v0));
+#pragma unroll
+                        for (int off = 1; off < kWave; off <<= 1) {
+                            const Aff<TC> p = shfl_down_aff(el, off);
+                            if (lane + off < kWave) el = compose(el, p);
+                        }
+                        acc = compose(acc, Aff<TC>{__shfl(el.a, 0, kWave), __shfl(el.b, 0, kWave), __shfl(el.h, 0, kWave)});
+                        if (first < kWave) break;
+                    }
+                    if (ok) carry = apply(acc, (TC)0);
+                    else {
+                        carry = (TC)__longlong_as_double(0x7ff8000000000000LL);
+                        if (lane == 0) hdr->error = 1u;
+                    }
+                    if (lane == 0) {
+                        lb_store(&myrec->x, lb_bits(apply(agg, carry)));
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        lb_store(&myrec->flag, 2ull);
+                    }
+                }
+                if (lane == 0) {
+                    // carries into the teams, last team first: what follows team tm is team tm+1 ... then `carry`
+                    TC x = carry;
+#pragma unroll
+                    for (int tm = kLbTeams - 1; tm >= 0; --tm) {
+                        s_xc[tm] = x;
+                        s_xv[tm] = (tm == kLbTeams - 1) ? carry_v : (Op::kNeedsNext ? sh[tm + 1 < kLbTeams ? tm + 1 : tm].v0[buf][0] : (TS)0);
+                        x = apply(tagg[tm], x);
+                    }
+                }
+            }
+            __syncthreads();
+            xc = s_xc[team];
+            xv = s_xv[team];
+        });
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+struct Plan {
+    bool ok;
+    bool long_rows, wave_indep, vec, interleaved, lookback;
+    int rows_per_chunk;
+    i64 nchunks;
+    i64 nblocks;
+};
+
+constexpr i64 kMaxLongGrid = 256 * 8;  // LONG geometry: blocks grid-stride over rows
+constexpr i64 kMaxShortGrid = 512;     // SHORT geometry: persistent blocks (<= 2 per CU)
+
+i64 gcd_i64(i64 a, i64 b) { while (b) { i64 t = a % b; a = b; b = t; } return a; }
+
+int device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
+// V: elements per lane; ptr_align_ok: every tensor base pointer is 16-byte aligned.
+Plan make_plan(i64 O, i64 T, i64 I, int V, bool ptr_align_ok, int cus, size_t lb_bytes = 0, bool want_partials = false) {
+    Plan p{};
+    const i64 chunk = (i64)kTeam * V;
+    if (I > 1) {
+        // interleaved feature dims: whole outer rows must fit a chunk
+        if (T * I > chunk || I > 1024) return p;
+        i64 R = chunk / (T * I);
+        const i64 q = V / gcd_i64(T * I, V);
+        if (R >= q) R -= R % q;
+        if (R > O) R = O;
+        p.ok = true;
+        p.interleaved = true;
+        p.rows_per_chunk = (int)R;
+        p.nchunks = (O + R - 1) / R;
+        i64 nb = p.nchunks;
+        if (nb > (i64)cus * 8) nb = (i64)cus * 8;
+        if (nb > 4096) nb = 4096;  // up to 8 resident teams per CU (15.0 vs 16.8 us at C3 with 4), chunks walked grid-stride
+        p.nblocks = nb;
+        p.vec = ptr_align_ok && (p.nchunks == 1 || (R * T * I) % V == 0);
+        p.wave_indep = ((i64)kWave * V) % T == 0;
+        return p;
+    }
+    if (T >= (1LL << 31) - 4096) return p;  // not this family's shape
+    p.ok = true;
+    if (T <= chunk) {
+        // R whole rows per chunk; prefer R*T multiple of V so every chunk start stays aligned
+        i64 R = chunk / T;
+        const i64 q = V / gcd_i64(T, V);
+        if (R >= q) R -= R % q;
+        if (R > O) R = O;
+        p.rows_per_chunk = (int)R;
+        p.nchunks = (O + R - 1) / R;
+        i64 nb = (p.nchunks + kTeams - 1) / kTeams;
+        if (nb > cus) nb = cus;  // one persistent block per CU; chunks beyond are walked grid-stride
+        if (nb > kMaxShortGrid) nb = kMaxShortGrid;
+        p.nblocks = nb;
+        p.vec = ptr_align_ok && (p.nchunks == 1 || (R * T) % V == 0);
+        p.wave_indep = ((i64)kWave * V) % T == 0;
+        p.long_rows = false;
+    } else {
+        p.long_rows = true;
+        p.nblocks = O < kMaxLongGrid ? O : kMaxLongGrid;
+        p.vec = ptr_align_ok && (T % V == 0);
+        p.wave_indep = false;
+        // too few rows to fill the chip (measured crossover: ~0.9 * #CUs rows; the in-block chunk loop streams
+        // ~13 GB/s per row): scan each row's chunks in parallel with decoupled look-back
+        const i64 lb_chunk = chunk * kLbTeams;  // steps per look-back block
+        const i64 nch = (T + lb_chunk - 1) / lb_chunk;
+        if (!want_partials && 8 * O < 7 * (i64)cus && O <= kLbMaxRows && T >= 8 * chunk && O * nch <= (1LL << 22) &&
+            lb_bytes >= sizeof(LbHeader) + (size_t)(O * nch) * sizeof(LbRecord)) {
+            p.lookback = true;
+            p.nchunks = nch;
+            p.nblocks = O * nch;
+        }
+    }
+    return p;
+}
+
+template <class Op>
+LaunchResult launch_scan(hipStream_t s, const typename Op::Args &a, const Plan &p, i64 O, i64 T, i64 I, double *partials,
+                         const char *name, void *lb_ws = nullptr) {
+    ScanGeom geo{O, T, p.rows_per_chunk, scan_lanes_for(T, Op::V, p.wave_indep), p.nchunks};
+    const dim3 grid((unsigned)p.nblocks);
+    if constexpr (Op::kShifted || Op::kReversed) {
+        if (p.interleaved) return LaunchResult{2, 0, nullptr};  // the shifted layout / the adjoints: I == 1 kernels only
+    }
+    if (p.interleaved) {
+      if constexpr (!Op::kShifted && !Op::kReversed) {
+        // bank-conflict padding of the LDS arrays ([8192x128x8] 90 -> 34 us, [8192x64x16] 55 -> 34, [8192x32x8] 11.5 -> 10.1,
+        // [8192x100x10] 41.3 -> 40.1; no effect for odd strides: [4096x100x5] 13.0 / 13.1)
+        const i64 stride_words = (i64)Op::V * I * (i64)(sizeof(typename Op::TS) / 4);  // between the lanes of one (o, i) row
+        const bool pad_lds = stride_words % 8 == 0;                                     // a row folds onto <= 4 of the 32 banks
+#define TRL_LAUNCH(VEC, WI)                                                                                                   \
+    do {                                                                                                                      \
+        if (pad_lds) hipLaunchKernelGGL((scan_interleaved_kernel<Op, VEC, WI, true>), grid, dim3(kTeam), 0, s, a, geo, (int)I, partials); \
+        else hipLaunchKernelGGL((scan_interleaved_kernel<Op, VEC, WI, false>), grid, dim3(kTeam), 0, s, a, geo, (int)I, partials);          \
+    } while (0)
+        if (p.wave_indep) { if (p.vec) TRL_LAUNCH(true, true); else TRL_LAUNCH(false, true); }
+        else              { if (p.vec) TRL_LAUNCH(true, false); else TRL_LAUNCH(false, false); }
+#undef TRL_LAUNCH
+      }
+    } else if (p.lookback) {
+        LbHeader *hdr = (LbHeader *)lb_ws;
+        LbRecord *rec = (LbRecord *)((char *)lb_ws + sizeof(LbHeader));
+        if (hipMemsetAsync(lb_ws, 0, sizeof(LbHeader) + (size_t)p.nblocks * sizeof(LbRecord), s) != hipSuccess)
+            return LaunchResult{4, 0, nullptr};
+        if (p.vec) hipLaunchKernelGGL((scan_lookback_kernel<Op, true>), grid, dim3(kLbTeams * kTeam), 0, s, a, geo, hdr, rec);
+        else hipLaunchKernelGGL((scan_lookback_kernel<Op, false>), grid, dim3(kLbTeams * kTeam), 0, s, a, geo, hdr, rec);
+    } else if (p.long_rows) {
+        if (p.vec) hipLaunchKernelGGL((scan_long_kernel<Op, true>), grid, dim3(kLongThreads), 0, s, a, geo, partials);
+        else hipLaunchKernelGGL((scan_long_kernel<Op, false>), grid, dim3(kLongThreads), 0, s, a, geo, partials);
+    } else {
+#define TRL_LAUNCH(VEC, WI) hipLaunchKernelGGL((scan_short_kernel<Op, VEC, WI>), grid, dim3(kShortThreads), 0, s, a, geo, partials)
+        if (p.wave_indep) { if (p.vec) TRL_LAUNCH(true, true); else TRL_LAUNCH(false, true); }
+        else              { if (p.vec) TRL_LAUNCH(true, false); else TRL_LAUNCH(false, false); }
+#undef TRL_LAUNCH
+    }
+    return LaunchResult{0, p.nblocks, name};
+}
+
+inline bool aligned16(const void *p) { return p == nullptr || (((uintptr_t)p) & 15) == 0; }
+
+template <template <typename, typename, int> class OpT, typename Args, typename F>
+LaunchResult dispatch_scan(int vdt, int cdt, F &&f) {
+    // V = 16 bytes of the storage dtype per lane
+    if (vdt == 0 && cdt == 0) return f(OpT<float, float, 4>{});
+    if (vdt == 1 && cdt == 1) return f(OpT<double, double, 2>{});
+    if (vdt == 1 && cdt == 0) return f(OpT<double, float, 2>{});
+    if (vdt == 0 && cdt == 1) return f(OpT<float, double, 4>{});
+    return LaunchResult{1, 0, nullptr};
+}
+
+}  // namespace

@@ -143,6 +143,49 @@ __global__ __launch_bounds__(kSeqThreads) void td_lambda_fixed_seq_kernel(TdLamb
     ret[jk] = (TS)g;
 }
 
+// TD(1) (functional.py:515-562).  FIXED = rolling_gamma=False: one lane per (o, k, i), the tail T-1..k rerun with
+// gamma_k held fixed and g starting from 0 (the reference's python int: no bootstrap from the last next value).
+template <typename TS, typename TG, bool FIXED>
+__global__ __launch_bounds__(kSeqThreads) void td1_seq_kernel(TdLambdaArgs a) {
+    using TC = typename Promote<TS, TG>::type;
+    const TS *__restrict__ r = (const TS *)a.reward;
+    const TS *__restrict__ nv = (const TS *)a.next_value;
+    const u8 *__restrict__ d = a.done;
+    const u8 *__restrict__ tm = a.terminated;
+    const TG *__restrict__ gt = (const TG *)a.gamma_t;
+    TS *__restrict__ ret = (TS *)a.returns;
+
+    const i64 idx = (i64)blockIdx.x * kSeqThreads + threadIdx.x;
+    i64 o, i, k = 0;
+    if (FIXED) {
+        if (idx >= a.O * a.T * a.I) return;
+        o = idx / (a.T * a.I);
+        const i64 rem = idx - o * a.T * a.I;
+        k = rem / a.I;
+        i = rem - k * a.I;
+    } else {
+        if (idx >= a.O * a.I) return;
+        o = idx / a.I;
+        i = idx - o * a.I;
+    }
+    const i64 jk = (o * a.T + k) * a.I + i;
+    const TG gk = gt ? gt[jk] : (TG)a.gamma;
+    i64 j = (o * a.T + (a.T - 1)) * a.I + i;
+    const i64 ms = a.mask_bcast ? 1 : a.I;
+    i64 mj = a.mask_bcast ? o * a.T + (a.T - 1) : j;
+    TC g = FIXED ? (TC)0 : (TC)nv[j];
+#pragma unroll 4
+    for (i64 t = a.T - 1; t >= k; --t, j -= a.I, mj -= ms) {
+        const TG gm = FIXED ? gk : (gt ? gt[j] : (TG)a.gamma);
+        const TG gnt = gm * (TG)(tm[mj] ? 0 : 1);
+        const bool b = d[mj] && !tm[mj];
+        const TS dnt = (TS)(b ? 1 : 0), omdnt = (TS)(b ? 0 : 1);
+        g = (TC)r[j] + (TC)gnt * ((TC)omdnt * g + (TC)(dnt * nv[j]));
+        if (!FIXED) ret[j] = (TS)g;
+    }
+    if (FIXED) ret[jk] = (TS)g;
+}
+
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ T clamp_max_nan(T x, T hi) {  // torch.clamp_max: NaN propagates
@@ -165,7 +208,9 @@ __global__ __launch_bounds__(kSeqThreads) void vtrace_seq_kernel(VtraceArgs a) {
     TC *__restrict__ adv = (TC *)a.advantage;
     TC *__restrict__ vs_out = (TC *)a.vs;
     const TG gs = (TG)a.gamma;
-    const TS rho_hi = (TS)a.rho_thresh, c_hi = (TS)a.c_thresh;
+    const TS rho_s = (TS)a.rho_thresh, c_s = (TS)a.c_thresh;
+    const TS *__restrict__ rho_t = (const TS *)a.rho_t;  // optional per-element thresholds (rho.clamp_max(tensor))
+    const TS *__restrict__ c_t = (const TS *)a.c_t;
 
     const i64 idx = (i64)blockIdx.x * kSeqThreads + threadIdx.x;
     if (idx >= a.O * a.I) return;
@@ -185,8 +230,8 @@ __global__ __launch_bounds__(kSeqThreads) void vtrace_seq_kernel(VtraceArgs a) {
         const TG dd = g * (TG)(d[mj] ? 0 : 1);
         const TG td = g * (TG)(tm[mj] ? 0 : 1);
         const TS rho = exp_t(lp[j] - lmu[j]);
-        const TS crho = clamp_max_nan(rho, rho_hi);
-        const TS cc = clamp_max_nan(rho, c_hi);
+        const TS crho = clamp_max_nan(rho, rho_t ? rho_t[j] : rho_s);
+        const TS cc = clamp_max_nan(rho, c_t ? c_t[j] : c_s);
         const TC delta = (TC)crho * (((TC)r[j] + (TC)td * (TC)nv[j]) - (TC)v[j]);
         x = delta + ((TC)dd * (TC)cc) * x;
         const TC vs = x + (TC)v[j];
@@ -229,6 +274,22 @@ LaunchResult launch_td_lambda_seq(hipStream_t s, int vdt, int cdt, const TdLambd
         }
         hipLaunchKernelGGL((td_lambda_fixed_seq_kernel<TS, TG>), dim3((unsigned)nb), dim3(kSeqThreads), 0, s, a);
         return LaunchResult{0, 0, "td_lambda_fixed_seq"};
+    });
+}
+
+LaunchResult launch_td1_seq(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, int rolling) {
+    const i64 n = rolling ? a.O * a.I : a.O * a.T * a.I;
+    const i64 nb = (n + kSeqThreads - 1) / kSeqThreads;
+    if (!grid_ok(nb)) return LaunchResult{1, 0, nullptr};
+    return dispatch_types(vdt, cdt, [&](auto ts, auto tg) {
+        using TS = decltype(ts);
+        using TG = decltype(tg);
+        if (rolling) {
+            hipLaunchKernelGGL((td1_seq_kernel<TS, TG, false>), dim3((unsigned)nb), dim3(kSeqThreads), 0, s, a);
+            return LaunchResult{0, 0, "td1_seq"};
+        }
+        hipLaunchKernelGGL((td1_seq_kernel<TS, TG, true>), dim3((unsigned)nb), dim3(kSeqThreads), 0, s, a);
+        return LaunchResult{0, 0, "td1_fixed_seq"};
     });
 }
 

@@ -31,7 +31,6 @@ import struct
 import math
 import warnings
 from dataclasses import dataclass
-from functools import wraps
 from typing import Optional, Tuple, Union
 
 import torch
@@ -65,53 +64,6 @@ _DT = {torch.float32: 0, torch.float64: 1}
 # ---------------------------------------------------------------------------------------------
 # time-dim handling
 # ---------------------------------------------------------------------------------------------
-def _transpose_time(fun):
-    """Same contract as the reference decorator (functional.py:49-113): pops the ``time_dim``
-    keyword, brings time to dim -2 on every tensor argument with more than one element, and
-    transposes the outputs back.  Used by the estimators that are plain torch compositions
-    (``td0``/``td1``/``reward2go`` rows); the kernel-backed estimators canonicalise directly."""
-
-    @wraps(fun)
-    def transposed_fun(*args, **kwargs):
-        time_dim = kwargs.pop("time_dim", -2)
-
-        def transpose_tensor(tensor):
-            if not isinstance(tensor, torch.Tensor) or tensor.numel() <= 1:
-                return tensor, False
-            timedim = time_dim - tensor.ndim if time_dim >= 0 else time_dim
-            if timedim < -tensor.ndim or timedim >= 0:
-                raise RuntimeError(_TIME_ERR.format(tensor.shape, timedim))
-            if tensor.ndim >= 2:
-                return tensor.transpose(timedim, -2), False
-            if tensor.ndim == 1 and timedim == -1:
-                return tensor.unsqueeze(-1), True
-            raise RuntimeError(_TIME_ERR.format(tensor.shape, timedim))
-
-        if time_dim != -2:
-            single_dim = False
-            if args:
-                args, sd = zip(*(transpose_tensor(arg) for arg in args))
-                single_dim = any(sd)
-            for k, item in list(kwargs.items()):
-                item, sd = transpose_tensor(item)
-                single_dim = single_dim or sd
-                kwargs[k] = item
-            out = fun(*args, **kwargs)
-            if isinstance(out, torch.Tensor):
-                out = transpose_tensor(out)[0]
-                return out.squeeze(-2) if single_dim else out
-            if single_dim:
-                return tuple(transpose_tensor(_out)[0].squeeze(-2) for _out in out)
-            return tuple(transpose_tensor(_out)[0] for _out in out)
-        out = fun(*args, **kwargs)
-        for _out in out if isinstance(out, tuple) else (out,):
-            if _out.ndim < 2:
-                raise RuntimeError(_TIME_ERR.format(_out.shape, time_dim))
-        return out
-
-    return transposed_fun
-
-
 def _canonical_dims(shape, time_dim: int) -> Tuple[int, int, int, int]:
     """``(O, T, I, td)`` for a ``[*B, T, *F]`` tensor with time at ``time_dim``; ``td`` is the
     non-negative index of the time dim.  Raises the reference's time-dim ``RuntimeError``."""
@@ -363,8 +315,9 @@ def _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, term
         cdt = torch.promote_types(g_dt, lg_dt)
     if cdt not in _DT:
         raise NotImplementedError(f"gamma / lmbda dtype {cdt} is not supported (float32 / float64 only)")
-    grads = _needs_grad(state_value, next_state_value, reward)
-    d8, t8, bcast = _masks(done, terminated, shape, time_dim, dev, grads)
+    # a differentiable call keeps both value tensors (the backward kernels read the dense layout); compact masks are fine
+    grads = _needs_grad(state_value, next_state_value, reward, gamma, lmbda)
+    d8, t8, bcast = _masks(done, terminated, shape, time_dim, dev, False)
     shifted = _shifted_pair(state_value, next_state_value, shape, time_dim, vdt, grads)
     return _GaeCall(
         shape=shape, O=O, T=T, I=I, vdt=vdt, cdt=cdt, out_dtype=next_state_value.dtype,
@@ -465,31 +418,33 @@ def _launch_gae_normalize(c: _GaeCall, eps: float, algo: int = ALGO_AUTO, out=No
 # ---------------------------------------------------------------------------------------------
 # autograd: the adjoint of a reverse affine scan is a forward scan with the same coefficients
 # ---------------------------------------------------------------------------------------------
-# Forward x_t = b_t + a_t x_{t+1}  =>  G_t = dL/db_t = gbar_t + a_{t-1} G_{t-1}, G_{-1} = 0.  In the
-# time-reversed index u = T-1-t this is again a reverse scan, G'_u = gbar'_u + a'_{u+1} G'_{u+1}, so the
-# backward pass runs on the SAME HIP kernels (trl_gae_fwd with value = next_value = 0 and every step
-# "terminated", which makes delta = gbar' exactly) on flipped inputs with the masks shifted by one
-# step.  Gradients flow to reward / state_value / next_state_value (reference behaviour under
-# differentiable=True, test/test_cost.py:15521-15584) and to gamma / lmbda tensors that require grad
-# (per-element products of G with the saved outputs; autograd sums them over the broadcast dims).
-# V-trace: _VtraceFunction below (also to log_pi / log_mu / gamma).
-def _adjoint_scan(gbar3: torch.Tensor, done3: torch.Tensor, lg3: Optional[torch.Tensor], lg: float, cdt) -> torch.Tensor:
-    """G (O,T,I) from gbar (O,T,I): G_t = gbar_t + (lg_{t-1} * (1-done_{t-1})) * G_{t-1}."""
-    O, T, I = gbar3.shape
-    dev = gbar3.device
-    gb = gbar3.flip(1).contiguous()
-    dflip = done3.flip(1)
-    dshift = torch.cat([dflip[:, 1:], torch.ones_like(dflip[:, :1])], 1).contiguous()
-    lgs = None
-    if lg3 is not None:
-        lf = lg3.flip(1)
-        lgs = torch.cat([lf[:, 1:], torch.zeros_like(lf[:, :1])], 1).contiguous()
-    zeros = torch.zeros_like(gb)
-    call = _GaeCall(shape=(O, T, I), O=O, T=T, I=I, vdt=gb.dtype, cdt=cdt, out_dtype=gb.dtype, reward=gb, value=zeros,
-                    next_value=zeros, done=dshift, terminated=torch.ones_like(dshift), gamma_t=lgs, lg_t=lgs,
-                    gamma=0.0, lmbda=0.0, lg=lg)
-    G, _, _ = _launch_gae(call)
-    return G.flip(1)
+# Forward x_t = b_t + a_t x_{t+1}  =>  G_t = dL/db_t = gbar_t + a_{t-1} G_{t-1}, G_{-1} = 0.  The backward passes are
+# HIP kernels behind the C ABI (trl_gae_bwd / trl_td_lambda_bwd / trl_td1_bwd / trl_vtrace_bwd, csrc/bwd_kernels.hip):
+# they read the incoming gradients and the masks / coefficients once and write every gradient once.  Gradients flow to
+# reward / state_value / next_state_value (reference behaviour under differentiable=True, test/test_cost.py:15521-15584),
+# to V-trace's log-probabilities, and to gamma / lmbda tensors that require grad (per-element products of the adjoint G
+# with the saved outputs -- elementwise torch ops on G; autograd sums them over the broadcast dims).
+_BWD_ALGO = ALGO_AUTO  # kernel family of the backward calls (tests pin SEQ / SCAN)
+
+
+def _grad_in(g, c, dt):
+    """Incoming gradient as a contiguous tensor of dtype ``dt`` (None stays None: the kernels read zeros)."""
+    if g is None:
+        return None
+    g = g.detach()
+    if g.dtype != dt:
+        g = g.to(dt)
+    return g.contiguous()
+
+
+def _m3(c, m):
+    """A mask of the call as a view that broadcasts against (O, T, I) (compact (O, T) masks: mask_bcast)."""
+    return m.view(c.O, c.T, 1 if c.mask_bcast else c.I)
+
+
+def _bwd_ws(lib, c):
+    ws = _lookback_workspace(lib, c.reward.device, c.O, c.T, c.I)
+    return _ptr(ws), (ws.numel() if ws is not None else 0), ws
 
 
 def _coef_leaf(x, shape, time_dim):
@@ -517,6 +472,11 @@ def _coef_grad(g3, leaf, c):
     return None if leaf is None else g3.reshape(c.shape).to(leaf.dtype)
 
 
+def _next_in_time(x3, last):
+    """x_{t+1} along dim 1 with ``last`` (broadcastable to one step) after the final step."""
+    return torch.cat([x3[:, 1:], last.expand_as(x3[:, :1])], 1)
+
+
 class _GaeFunction(torch.autograd.Function):
     """``coefs = (gamma, lmbda, time_dim)`` as the caller passed them; ``gamma_e`` / ``lmbda_e`` are their
     differentiable full-shape views (:func:`_coef_leaf`) or None."""
@@ -539,31 +499,62 @@ class _GaeFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_adv, g_vt):
         c = ctx.call
-        shp3 = (c.O, c.T, c.I)
-        dt = torch.promote_types(c.vdt, c.cdt)
-        z = lambda g: torch.zeros(shp3, dtype=dt, device=c.reward.device) if g is None else g.to(dt).contiguous().view(shp3)
-        ga, gv = z(g_adv), z(g_vt)
-        done3 = c.done.view(shp3)
-        lg3 = None
-        if c.gamma_t is not None:
-            lg3 = (c.lg_t if c.lg_t is not None else c.gamma_t * _round_to(c.lmbda, c.cdt)).view(shp3).to(dt)
-        G = _adjoint_scan(ga + gv, done3, lg3, c.lg, c.cdt if dt == c.cdt else dt)
-        nt = (1 - c.terminated.view(shp3)).to(dt)
-        g_coef = c.gamma_t.view(shp3).to(dt) * nt if c.gamma_t is not None else nt * c.gamma
-        outs = (gv - G, G * g_coef, G)
-        d_gamma = d_lmbda = None
         gamma_e, lmbda_e = ctx.leaves
-        if gamma_e is not None or lmbda_e is not None:
+        want_coef = gamma_e is not None or lmbda_e is not None
+        none5 = (None, None, None, None, None)
+        if g_adv is None and g_vt is None:
+            return (None, None, None) + none5
+        lib = _extension.get_lib()
+        dev = c.reward.device
+        ga, gv = _grad_in(g_adv, c, c.vdt), _grad_in(g_vt, c, c.vdt)
+        need = ctx.needs_input_grad
+        new = lambda on: torch.empty(c.shape, dtype=c.vdt, device=dev) if on else None
+        d_v, d_nv, d_r = new(need[0]), new(need[1]), new(need[2] or want_coef)
+        if d_v is not None or d_nv is not None or d_r is not None:
+            wsp, wsb, _ws = _bwd_ws(lib, c)
+            with _on(dev):
+                rc = lib.trl_gae_bwd(_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(ga), _ptr(gv), _ptr(c.done), _ptr(c.terminated),
+                                     c.mask_bcast, _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg, c.O, c.T, c.I,
+                                     _ptr(d_r), _ptr(d_v), _ptr(d_nv), wsp, wsb, _BWD_ALGO)
+            _extension.check(rc, lib)
+        d_gamma = d_lmbda = None
+        if want_coef:
             # A_t = delta_t + (lmbda_t gamma_t (1 - done_t)) A_{t+1},  delta_t = r_t + gamma_t (1 - terminated_t) v'_t - v_t
+            shp3 = (c.O, c.T, c.I)
+            dt = torch.promote_types(c.vdt, c.cdt)
             (adv,) = ctx.saved_tensors
             A = adv.view(shp3).to(dt)
-            d_lg = G * (1 - done3).to(dt) * torch.cat([A[:, 1:], torch.zeros_like(A[:, :1])], 1)
+            G = d_r.view(shp3).to(dt)
+            nd, nt = (1 - _m3(c, c.done)).to(dt), (1 - _m3(c, c.terminated)).to(dt)
+            d_lg = G * nd * _next_in_time(A, torch.zeros((), dtype=dt, device=dev))
             gamma, lmbda, time_dim = ctx.coefs
             if gamma_e is not None:
                 d_gamma = _coef_grad(G * nt * c.next_value.view(shp3).to(dt) + d_lg * _coef_value(lmbda, c, dt, time_dim), gamma_e, c)
             if lmbda_e is not None:
                 d_lmbda = _coef_grad(d_lg * _coef_value(gamma, c, dt, time_dim), lmbda_e, c)
-        return tuple(o.to(d).view(s) for o, d, s in zip(outs, ctx.in_dtypes, ctx.in_shapes)) + (d_gamma, d_lmbda, None, None, None)
+        outs = tuple(None if o is None or not n else o.to(d).view(s)
+                     for o, n, d, s in zip((d_v, d_nv, d_r), need[:3], ctx.in_dtypes, ctx.in_shapes))
+        return outs + (d_gamma, d_lmbda, None, None, None)
+
+
+def _td_bwd(c, g_ret, td1: bool, need_nv: bool, need_r: bool):
+    """(d_next_state_value, d_reward) of TD(lambda) / TD(1) through trl_td_lambda_bwd / trl_td1_bwd."""
+    lib = _extension.get_lib()
+    dev = c.reward.device
+    gr = _grad_in(g_ret, c, c.vdt)
+    d_nv = torch.empty(c.shape, dtype=c.vdt, device=dev) if need_nv else None
+    d_r = torch.empty(c.shape, dtype=c.vdt, device=dev) if need_r else None
+    wsp, wsb, _ws = _bwd_ws(lib, c)
+    with _on(dev):
+        if td1:
+            rc = lib.trl_td1_bwd(_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(gr), _ptr(c.done), _ptr(c.terminated), c.mask_bcast,
+                                 _ptr(c.gamma_t), c.gamma, c.O, c.T, c.I, _ptr(d_r), _ptr(d_nv), wsp, wsb, _BWD_ALGO)
+        else:
+            rc = lib.trl_td_lambda_bwd(_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(gr), _ptr(c.done), _ptr(c.terminated), c.mask_bcast,
+                                       _ptr(c.gamma_t), _ptr(c.lmbda_t), c.gamma, c.lmbda, c.O, c.T, c.I, _ptr(d_r), _ptr(d_nv),
+                                       wsp, wsb, _BWD_ALGO)
+    _extension.check(rc, lib)
+    return d_nv, d_r
 
 
 class _TdLambdaFunction(torch.autograd.Function):
@@ -584,41 +575,79 @@ class _TdLambdaFunction(torch.autograd.Function):
         c = ctx.call
         if not c.rolling:
             raise NotImplementedError("backward of td_lambda_return_estimate(rolling_gamma=False) is not implemented")
-        shp3 = (c.O, c.T, c.I)
-        dt = torch.promote_types(c.vdt, c.cdt)
-        dev = c.reward.device
-        gr = g_ret.to(dt).contiguous().view(shp3)
-        done3 = c.done.view(shp3)
-        dn = done3.to(dt)
-        gam = c.gamma_t.view(shp3).to(dt) if c.gamma_t is not None else torch.full((), c.gamma, dtype=dt, device=dev)
-        lam = c.lmbda_t.view(shp3).to(dt) if c.lmbda_t is not None else torch.full((), c.lmbda, dtype=dt, device=dev)
-        tensor_coef = c.gamma_t is not None or c.lmbda_t is not None
-        lg3 = (gam * lam).expand(shp3).contiguous() if tensor_coef else None
-        G = _adjoint_scan(gr, done3, lg3, float(c.gamma * c.lmbda), dt)
-        # R_t = r_t + gamma_t((1-lmbda_t) v'_t + lmbda_t (g_{t+1} nd_t + v'_t d_t)); g_T := v'_{T-1}
-        d_nvm = G * gam * ((1 - lam) + lam * dn)
-        last = (G * gam * lam * (1 - dn))[:, -1]
-        d_nvm = torch.cat([d_nvm[:, :-1], (d_nvm[:, -1] + last).unsqueeze(1)], 1)
-        nt = (1 - c.terminated.view(shp3)).to(dt)
-        d_nv = d_nvm * nt
-        outs = (d_nv, G)
-        d_gamma = d_lmbda = None
         gamma_e, lmbda_e = ctx.leaves
-        if gamma_e is not None or lmbda_e is not None:
+        want_coef = gamma_e is not None or lmbda_e is not None
+        if g_ret is None:
+            return (None,) * 7
+        need = ctx.needs_input_grad
+        d_nv, d_r = _td_bwd(c, g_ret, False, need[0], need[1] or want_coef)
+        d_gamma = d_lmbda = None
+        if want_coef:
+            # R_t = r_t + gamma_t((1-lmbda_t) v'_t + lmbda_t (g_{t+1} nd_t + v'_t d_t)); g_T := v'_{T-1}  (v' masked by nt)
+            shp3 = (c.O, c.T, c.I)
+            dt = torch.promote_types(c.vdt, c.cdt)
+            dev = c.reward.device
             (ret,) = ctx.saved_tensors
             R = ret.view(shp3).to(dt)
+            G = d_r.view(shp3).to(dt)
+            dn = _m3(c, c.done).to(dt)
+            nt = (1 - _m3(c, c.terminated)).to(dt)
+            gam = c.gamma_t.view(shp3).to(dt) if c.gamma_t is not None else torch.full((), c.gamma, dtype=dt, device=dev)
+            lam = c.lmbda_t.view(shp3).to(dt) if c.lmbda_t is not None else torch.full((), c.lmbda, dtype=dt, device=dev)
             nvm = c.next_value.view(shp3).to(dt) * nt
-            g1 = torch.cat([R[:, 1:], nvm[:, -1:]], 1) * (1 - dn) + nvm * dn   # what lmbda_t multiplies at step t
+            g1 = _next_in_time(R, nvm[:, -1:]) * (1 - dn) + nvm * dn   # what lmbda_t multiplies at step t
             if gamma_e is not None:
                 d_gamma = _coef_grad(G * ((1 - lam) * nvm + lam * g1), gamma_e, c)
             if lmbda_e is not None:
                 d_lmbda = _coef_grad(G * gam * (g1 - nvm), lmbda_e, c)
-        return tuple(o.to(d).view(s) for o, d, s in zip(outs, ctx.in_dtypes, ctx.in_shapes)) + (d_gamma, d_lmbda, None, None, None)
+        outs = tuple(None if o is None or not n else o.to(d).view(s)
+                     for o, n, d, s in zip((d_nv, d_r), need[:2], ctx.in_dtypes, ctx.in_shapes))
+        return outs + (d_gamma, d_lmbda, None, None, None)
+
+
+class _Td1Function(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, next_state_value, reward, gamma_e, call, out_dtype):
+        ctx.call = call
+        ctx.in_dtypes = (next_state_value.dtype, reward.dtype)
+        ctx.in_shapes = (next_state_value.shape, reward.shape)
+        ctx.gamma_e = gamma_e
+        ret = _launch_td1(call, out_dtype)
+        if gamma_e is not None:
+            ctx.save_for_backward(ret)
+        return ret
+
+    @staticmethod
+    def backward(ctx, g_ret):
+        c = ctx.call
+        if not c.rolling:
+            raise NotImplementedError("backward of td1_return_estimate(rolling_gamma=False) is not implemented")
+        if g_ret is None:
+            return (None,) * 5
+        need = ctx.needs_input_grad
+        want_coef = ctx.gamma_e is not None
+        d_nv, d_r = _td_bwd(c, g_ret, True, need[0], need[1] or want_coef)
+        d_gamma = None
+        if want_coef:
+            # R_t = r_t + gamma_t nt_t ((1 - dnt_t) R_{t+1} + dnt_t v'_t),  R_T := v'_{T-1}
+            shp3 = (c.O, c.T, c.I)
+            dt = torch.promote_types(c.vdt, c.cdt)
+            (ret,) = ctx.saved_tensors
+            R = ret.view(shp3).to(dt)
+            G = d_r.view(shp3).to(dt)
+            nv = c.next_value.view(shp3).to(dt)
+            d8, t8 = _m3(c, c.done), _m3(c, c.terminated)
+            dnt = (d8 & (1 - t8)).to(dt)
+            nt = (1 - t8).to(dt)
+            d_gamma = _coef_grad(G * nt * ((1 - dnt) * _next_in_time(R, nv[:, -1:]) + dnt * nv), ctx.gamma_e, c)
+        outs = tuple(None if o is None or not n else o.to(d).view(s)
+                     for o, n, d, s in zip((d_nv, d_r), need[:2], ctx.in_dtypes, ctx.in_shapes))
+        return outs + (d_gamma, None, None)
 
 
 class _VtraceFunction(torch.autograd.Function):
-    """V-trace with gradients to state_value / next_state_value / reward / log_pi / log_mu.  Forward on
-    trl_vtrace_fwd; backward = elementwise torch ops + ONE adjoint scan on the HIP scan kernels."""
+    """V-trace with gradients to log_pi / log_mu / state_value / next_state_value / reward (and a gamma tensor).
+    Forward on trl_vtrace_fwd; backward = ONE launch of trl_vtrace_bwd."""
 
     @staticmethod
     def forward(ctx, log_pi, log_mu, state_value, next_state_value, reward, gamma_e, call):
@@ -632,40 +661,26 @@ class _VtraceFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_adv, g_vs):
         c = ctx.call
+        if g_adv is None and g_vs is None:
+            return (None,) * 7
         (vs,) = ctx.saved_tensors
-        shp3 = (c.O, c.T, c.I)
-        dt = torch.promote_types(c.vdt, c.cdt)
+        lib = _extension.get_lib()
         dev = c.reward.device
-        z = lambda g: torch.zeros(shp3, dtype=dt, device=dev) if g is None else g.to(dt).contiguous().view(shp3)
-        A, S = z(g_adv), z(g_vs)
-        v3 = lambda t: t.view(shp3).to(dt)
-        lp, lm, v, nv, r = v3(c.log_pi), v3(c.log_mu), v3(c.value), v3(c.next_value), v3(c.reward)
-        vs3 = vs.view(shp3).to(dt)
-        nd, nt = (1 - c.done.view(shp3)).to(dt), (1 - c.terminated.view(shp3)).to(dt)
-        gam = v3(c.gamma_t) if c.gamma_t is not None else torch.full((), c.gamma, dtype=dt, device=dev)
-        rho = (lp - lm).exp()
-        rb, cb = rho.clamp_max(c.rho_thresh), rho.clamp_max(c.c_thresh)
-        g_nt, g_nd = gam * nt, gam * nd
-        vsp = torch.cat([vs3[:, 1:], nv[:, -1:]], 1)          # functional.py:1343-1345: the shift ignores done
-        d_rb = A * (r + g_nt * vsp - v)
-        d_vsp = A * rb * g_nt
-        s_tot = S + torch.cat([torch.zeros_like(d_vsp[:, :1]), d_vsp[:, :-1]], 1)
-        a = (g_nd * cb).expand(shp3).contiguous()              # x_t = delta_t + a_t x_{t+1}
-        X = _adjoint_scan(s_tot, torch.zeros(shp3, dtype=torch.bool, device=dev).view(torch.uint8), a, 0.0, dt)
-        x_next = torch.cat([(vs3 - v)[:, 1:], torch.zeros_like(v[:, :1])], 1)
-        d_rb = d_rb + X * (r + g_nt * nv - v)
-        d_cb = X * x_next * g_nd
-        d_rho = d_rb * (rho <= c.rho_thresh).to(dt) + d_cb * (rho <= c.c_thresh).to(dt)
-        d_lp = d_rho * rho
-        w = (A + X) * rb
-        d_nv = X * rb * g_nt
-        d_nv = torch.cat([d_nv[:, :-1], d_nv[:, -1:] + d_vsp[:, -1:]], 1)
-        outs = (d_lp, -d_lp, s_tot - w, d_nv, w)
-        res = [o.reshape(c.shape).to(d) for o, (d, _) in zip(outs, ctx.ins)]
-        d_gamma = None
-        if ctx.gamma_e is not None:  # gamma enters as gamma * not_terminated (delta, advantage) and gamma * not_done (trace)
-            d_gamma = _coef_grad(nt * rb * (A * vsp + X * nv) + nd * X * x_next * cb, ctx.gamma_e, c)
-        return tuple(res) + (d_gamma, None)
+        odt = torch.promote_types(c.vdt, c.cdt)
+        ga, gs = _grad_in(g_adv, c, odt), _grad_in(g_vs, c, odt)
+        need = ctx.needs_input_grad
+        new = lambda on, dt=c.vdt: torch.empty(c.shape, dtype=dt, device=dev) if on else None
+        outs = [new(n) for n in need[:5]]
+        d_gamma_t = new(ctx.gamma_e is not None, odt)
+        wsp, wsb, _ws = _bwd_ws(lib, c)
+        with _on(dev):
+            rc = lib.trl_vtrace_bwd(_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(ga), _ptr(gs), _ptr(c.log_pi), _ptr(c.log_mu),
+                                    _ptr(c.value), _ptr(c.next_value), _ptr(c.reward), _ptr(vs.contiguous()), _ptr(c.done),
+                                    _ptr(c.terminated), c.mask_bcast, _ptr(c.gamma_t), c.gamma, c.rho_thresh, c.c_thresh,
+                                    _ptr(c.rho_t), _ptr(c.c_t), c.O, c.T, c.I, *(_ptr(o) for o in outs), _ptr(d_gamma_t), wsp, wsb, _BWD_ALGO)
+        _extension.check(rc, lib)
+        res = tuple(None if o is None else o.to(d).view(s) for o, (d, s) in zip(outs, ctx.ins))
+        return res + (_coef_grad(d_gamma_t, ctx.gamma_e, c) if d_gamma_t is not None else None, None)
 
 
 def _geom_series_like(t: torch.Tensor, r, thr: float) -> torch.Tensor:
@@ -968,7 +983,7 @@ def _prepare_td_lambda(gamma, lmbda, next_state_value, reward, done, terminated,
         g_t = g_t.to(device=dev, dtype=cdt).contiguous()
     if l_t is not None:
         l_t = l_t.to(device=dev, dtype=cdt).contiguous()
-    masks = _masks(done, terminated, shape, time_dim, dev, _needs_grad(next_state_value, reward))
+    masks = _masks(done, terminated, shape, time_dim, dev, False)
     return _TdLambdaCall(shape=shape, O=O, T=T, I=I, vdt=vdt, cdt=cdt, reward=_val(reward, vdt, dev),
                          next_value=_val(next_state_value, vdt, dev), done=masks[0],
                          terminated=masks[1], mask_bcast=masks[2], gamma_t=g_t, lmbda_t=l_t, gamma=g_val,
@@ -1135,15 +1150,20 @@ class _VtraceCall:
     rho_thresh: float
     c_thresh: float
     mask_bcast: int = 0
+    rho_t: Optional[torch.Tensor] = None  # per-element thresholds (a broadcastable threshold tensor was passed)
+    c_t: Optional[torch.Tensor] = None
 
 
-def _thresh(x) -> float:
-    # functional.py:1311-1314: python thresholds become 0-dim default-dtype tensors
+def _thresh(x, shape, time_dim, vdt, dev):
+    """``(scalar, tensor)`` form of a V-trace clipping threshold.  functional.py:1311-1330: python thresholds become
+    0-dim default-dtype tensors; a tensor goes to ``rho.clamp_max(tensor)`` as it is, i.e. it broadcasts against the
+    (time-transposed) inputs -- handed to the kernels as a per-element tensor in the value dtype."""
     if isinstance(x, torch.Tensor):
-        if x.numel() != 1:
-            raise NotImplementedError("vtrace_advantage_estimate: per-element clipping thresholds are not supported")
-        return float(x)
-    return _round_to(float(x), torch.get_default_dtype())
+        if x.numel() == 1:
+            return float(x), None
+        full = x.detach() if tuple(x.shape) == tuple(shape) else _expand_coef(x.detach(), shape, time_dim)
+        return 0.0, full.to(device=dev, dtype=vdt).contiguous()
+    return _round_to(float(x), torch.get_default_dtype()), None
 
 
 def _prepare_vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward, done, terminated, rho_thresh,
@@ -1169,14 +1189,19 @@ def _prepare_vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward
     def bc(t):
         return t if tuple(t.shape) == shape else _expand_coef(t, shape, time_dim)
 
-    grads = _needs_grad(log_pi, log_mu, state_value, next_state_value, reward)
-    masks = _masks(done, terminated, shape, time_dim, dev, grads)
+    grads = _needs_grad(log_pi, log_mu, state_value, next_state_value, reward, gamma)
+    masks = _masks(done, terminated, shape, time_dim, dev, False)
     shifted = _shifted_pair(state_value, next_state_value, shape, time_dim, vdt, grads)
+    rho_s, rho_t = _thresh(rho_thresh, shape, time_dim, vdt, dev)
+    c_s, c_t = _thresh(c_thresh, shape, time_dim, vdt, dev)
+    if rho_t is not None or c_t is not None:  # SEQ family: dense layout, full masks
+        shifted = False
+        masks = _masks(done, terminated, shape, time_dim, dev, True)
     return _VtraceCall(shape=shape, O=O, T=T, I=I, vdt=vdt, cdt=cdt, log_pi=_val(bc(log_pi), vdt, dev),
                        log_mu=_val(bc(log_mu), vdt, dev), value=state_value.detach() if shifted else _val(state_value, vdt, dev),
                        next_value=None if shifted else _val(next_state_value, vdt, dev), reward=_val(reward, vdt, dev),
                        done=masks[0], terminated=masks[1], mask_bcast=masks[2], gamma_t=gamma_t,
-                       gamma=g_val, rho_thresh=_thresh(rho_thresh), c_thresh=_thresh(c_thresh))
+                       gamma=g_val, rho_thresh=rho_s, c_thresh=c_s, rho_t=rho_t, c_t=c_t)
 
 
 def _launch_vtrace(c: _VtraceCall, algo: int = ALGO_AUTO):
@@ -1193,7 +1218,7 @@ def _launch_vtrace(c: _VtraceCall, algo: int = ALGO_AUTO):
         rc = lib.trl_vtrace_fwd(
             _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.log_pi), _ptr(c.log_mu), _ptr(c.value), _ptr(c.next_value),
             _ptr(c.reward), _ptr(c.done), _ptr(c.terminated), c.mask_bcast, _ptr(c.gamma_t), c.gamma, c.rho_thresh, c.c_thresh,
-            c.O, c.T, c.I, _ptr(adv), _ptr(vs), _ptr(ws), ws.numel() if ws is not None else 0, algo)
+            _ptr(c.rho_t), _ptr(c.c_t), c.O, c.T, c.I, _ptr(adv), _ptr(vs), _ptr(ws), ws.numel() if ws is not None else 0, algo)
     _extension.check(rc, lib)
     return adv, vs
 
@@ -1227,8 +1252,9 @@ def vtrace_advantage_estimate(
 
 
 # ---------------------------------------------------------------------------------------------
-# TD(0), TD(1), reward-to-go -- "next" rows of SURVEY.md 8(f): thin compositions over the
-# kernels above (TD(1) is TD(lambda) with lmbda = 1, exactly as functional.py:691-700 does).
+# TD(0), TD(1), reward-to-go -- "next" rows of SURVEY.md 8(f).  TD(1) has its own kernels (trl_td1_fwd: the
+# reference's TD(1) loops differ from TD(lambda) at lmbda = 1 in the start value and in how masks enter);
+# vec TD(1) is vec TD(lambda) with lmbda = 1, exactly as functional.py:691-700 does.
 # ---------------------------------------------------------------------------------------------
 def td0_return_estimate(
     gamma: float,
@@ -1277,6 +1303,49 @@ def vec_td1_return_estimate(
                                          terminated=terminated, rolling_gamma=rolling_gamma, lmbda=1, time_dim=time_dim)
 
 
+def _prepare_td1(gamma, next_state_value, reward, done, terminated, rolling_gamma, time_dim) -> _TdLambdaCall:
+    """Host logic of TD(1) (functional.py:515-536): a gamma of the inputs' shape is per-element, anything else becomes
+    ``torch.full_like(next_state_value, gamma)``."""
+    if terminated is None:
+        terminated = done
+    if not (next_state_value.shape == reward.shape == done.shape == terminated.shape):
+        raise RuntimeError(SHAPE_ERR)
+    shape = tuple(next_state_value.shape)
+    O, T, I, _ = _canonical_dims(shape, time_dim)
+    vdt = _check_value_dtype(reward, next_state_value)
+    dev = next_state_value.device
+    g_t, g_val, cdt = _td_coef(gamma, shape, vdt, "gamma")
+    if rolling_gamma is None:
+        rolling_gamma = True
+    elif not rolling_gamma and g_t is None:
+        raise RuntimeError("rolling_gamma=False is expected only with time-sensitive gamma values")
+    if cdt not in _DT:
+        raise NotImplementedError(f"gamma dtype {cdt} is not supported (float32 / float64 only)")
+    if g_t is not None:
+        g_t = g_t.to(device=dev, dtype=cdt).contiguous()
+    masks = _masks(done, terminated, shape, time_dim, dev, False)
+    return _TdLambdaCall(shape=shape, O=O, T=T, I=I, vdt=vdt, cdt=cdt, reward=_val(reward, vdt, dev),
+                         next_value=_val(next_state_value, vdt, dev), done=masks[0], terminated=masks[1],
+                         mask_bcast=masks[2], gamma_t=g_t, lmbda_t=None, gamma=g_val, lmbda=1.0, rolling=bool(rolling_gamma))
+
+
+def _launch_td1(c: _TdLambdaCall, out_dtype, algo: int = ALGO_AUTO) -> torch.Tensor:
+    lib = _extension.get_lib()
+    _require_hip(c.reward)
+    dev = c.reward.device
+    out = torch.empty(c.shape, dtype=c.vdt, device=dev)
+    if c.O * c.T * c.I == 0:
+        return out.to(out_dtype)
+    ws = _lookback_workspace(lib, dev, c.O, c.T, c.I) if c.rolling else None
+    with _on(dev):
+        rc = lib.trl_td1_fwd(
+            _stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.next_value), _ptr(c.done), _ptr(c.terminated),
+            c.mask_bcast, _ptr(c.gamma_t), c.gamma, 1 if c.rolling else 0, c.O, c.T, c.I, _ptr(out),
+            _ptr(ws), ws.numel() if ws is not None else 0, algo)
+    _extension.check(rc, lib)
+    return out if out_dtype == c.vdt else out.to(out_dtype)
+
+
 def td1_return_estimate(
     gamma: float,
     next_state_value: torch.Tensor,
@@ -1289,18 +1358,14 @@ def td1_return_estimate(
 ) -> torch.Tensor:
     """TD(1) return estimate (reference: functional.py:464-562).
 
-    The reference loop ``g = r + gamma*nt*((1-dnt)*g + dnt*v')`` with ``dnt = done & ~terminated``
-    equals the TD(lambda) recurrence at ``lmbda = 1`` (``g <- g*(1-done) + v'*nt*done`` then
-    ``g = r + gamma*g``) for 0/1 masks; it runs on the TD(lambda) kernels."""
-    if terminated is None:
-        terminated = done
-    if not (next_state_value.shape == reward.shape == done.shape == terminated.shape):
-        raise RuntimeError(SHAPE_ERR)
-    single_gamma = not (isinstance(gamma, torch.Tensor) and gamma.shape == done.shape)
-    if rolling_gamma is not None and not rolling_gamma and single_gamma:
-        raise RuntimeError("rolling_gamma=False is expected only with time-sensitive gamma values")
-    return td_lambda_return_estimate(gamma, 1.0, next_state_value, reward, done, terminated,
-                                     rolling_gamma if not single_gamma else None, time_dim=time_dim)
+    ``g = r + gamma*nt*((1-dnt)*g + dnt*v')`` with ``dnt = done & ~terminated``, starting from the raw
+    ``v'_{T-1}``; ``rolling_gamma=False`` (needs a gamma tensor of the inputs' shape) reruns every tail with
+    its first step's gamma from ``g = 0``, as the reference's loop does (``trl_td1_fwd``)."""
+    call = _prepare_td1(gamma, next_state_value, reward, done, terminated, rolling_gamma, time_dim)
+    if _needs_grad(next_state_value, reward, gamma):
+        return _Td1Function.apply(next_state_value, reward, _coef_leaf(gamma, call.shape, time_dim), call,
+                                  next_state_value.dtype)
+    return _launch_td1(call, next_state_value.dtype)
 
 
 def td1_advantage_estimate(
