@@ -59,8 +59,7 @@ def test_gae_grads_golden(meta, bwd_algo):
         ins = [r, v, nv] + [x for x in (gl, ll) if x is not None]
         names = ["reward", "state_value", "next_state_value"] + [n for n, x in (("gamma", gl), ("lmbda", ll)) if x is not None]
         compare(torch.autograd.grad(loss, ins), a, names)
-        if bwd_algo == F.ALGO_SEQ:
-            assert F.last_kernel() == "gae_bwd_seq" or gl is not None or ll is not None
+        assert F.last_bwd_kernel() == ("gae_bwd_seq" if bwd_algo == F.ALGO_SEQ or meta["shape"][-1] != 1 else "gae_bwd_scan")
     # a single requested gradient / a single incoming gradient
     adv, vt = F.generalized_advantage_estimate(g, l, v, nv, r, a["done"].to(DEV), a["terminated"].to(DEV), **kw(meta))
     (dr,) = torch.autograd.grad((adv * a["w_advantage"].to(DEV)).sum() + (vt * a["w_value_target"].to(DEV)).sum(), [r])
@@ -127,7 +126,7 @@ def test_scan_and_seq_backward_agree(shape, dtype, monkeypatch):
         out = []
         adv, vt = F.generalized_advantage_estimate(gam, 0.95, v, nv, r, done, term)
         out += list(torch.autograd.grad((adv * wa).sum() + (vt * wv).sum(), [r, v, nv]))
-        assert ("scan" in F.last_kernel()) == (algo == F.ALGO_SCAN), F.last_kernel()
+        assert ("scan" in F.last_bwd_kernel()) == (algo == F.ALGO_SCAN), F.last_bwd_kernel()
         ret = F.td_lambda_return_estimate(gam, 0.95, nv, r, done, term)
         out += list(torch.autograd.grad((ret * wa).sum(), [r, nv]))
         ret = F.td1_return_estimate(gam, nv, r, done, term)
@@ -151,6 +150,6 @@ def test_gae_backward_adjoint_identity_full_size():
     adv, vt = F.generalized_advantage_estimate(0.99, 0.95, v, nv, r, done, term)
     lhs = (adv * wa).sum() + (vt * wv).sum()
     dr, dv, dnv = torch.autograd.grad(lhs, [r, v, nv])
-    assert F.last_kernel() == "gae_bwd_scan"
+    assert F.last_bwd_kernel() == "gae_bwd_scan"
     rhs = (dr * r).sum() + (dv * v).sum() + (dnv * nv).sum()
     torch.testing.assert_close(lhs.detach(), rhs.detach(), rtol=1e-10, atol=1e-6)

@@ -425,6 +425,19 @@ def _launch_gae_normalize(c: _GaeCall, eps: float, algo: int = ALGO_AUTO, out=No
 # to V-trace's log-probabilities, and to gamma / lmbda tensors that require grad (per-element products of the adjoint G
 # with the saved outputs -- elementwise torch ops on G; autograd sums them over the broadcast dims).
 _BWD_ALGO = ALGO_AUTO  # kernel family of the backward calls (tests pin SEQ / SCAN)
+_LAST_BWD_KERNEL = ""
+
+
+def last_bwd_kernel() -> str:
+    """Kernel family of the last backward call.  (autograd runs backward on its own thread and trl_last_kernel is
+    per thread, so the backward Functions record the name themselves.)"""
+    return _LAST_BWD_KERNEL
+
+
+def _bwd_done(rc, lib):
+    global _LAST_BWD_KERNEL
+    _extension.check(rc, lib)
+    _LAST_BWD_KERNEL = lib.trl_last_kernel().decode()
 
 
 def _grad_in(g, c, dt):
@@ -516,7 +529,7 @@ class _GaeFunction(torch.autograd.Function):
                 rc = lib.trl_gae_bwd(_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(ga), _ptr(gv), _ptr(c.done), _ptr(c.terminated),
                                      c.mask_bcast, _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg, c.O, c.T, c.I,
                                      _ptr(d_r), _ptr(d_v), _ptr(d_nv), wsp, wsb, _BWD_ALGO)
-            _extension.check(rc, lib)
+            _bwd_done(rc, lib)
         d_gamma = d_lmbda = None
         if want_coef:
             # A_t = delta_t + (lmbda_t gamma_t (1 - done_t)) A_{t+1},  delta_t = r_t + gamma_t (1 - terminated_t) v'_t - v_t
@@ -553,7 +566,7 @@ def _td_bwd(c, g_ret, td1: bool, need_nv: bool, need_r: bool):
             rc = lib.trl_td_lambda_bwd(_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(gr), _ptr(c.done), _ptr(c.terminated), c.mask_bcast,
                                        _ptr(c.gamma_t), _ptr(c.lmbda_t), c.gamma, c.lmbda, c.O, c.T, c.I, _ptr(d_r), _ptr(d_nv),
                                        wsp, wsb, _BWD_ALGO)
-    _extension.check(rc, lib)
+    _bwd_done(rc, lib)
     return d_nv, d_r
 
 
@@ -678,7 +691,7 @@ class _VtraceFunction(torch.autograd.Function):
                                     _ptr(c.value), _ptr(c.next_value), _ptr(c.reward), _ptr(vs.contiguous()), _ptr(c.done),
                                     _ptr(c.terminated), c.mask_bcast, _ptr(c.gamma_t), c.gamma, c.rho_thresh, c.c_thresh,
                                     _ptr(c.rho_t), _ptr(c.c_t), c.O, c.T, c.I, *(_ptr(o) for o in outs), _ptr(d_gamma_t), wsp, wsb, _BWD_ALGO)
-        _extension.check(rc, lib)
+        _bwd_done(rc, lib)
         res = tuple(None if o is None else o.to(d).view(s) for o, (d, s) in zip(outs, ctx.ins))
         return res + (_coef_grad(d_gamma_t, ctx.gamma_e, c) if d_gamma_t is not None else None, None)
 
@@ -1074,11 +1087,17 @@ def vec_td_lambda_return_estimate(
     if _is_scalar(gamma) and _is_scalar(lmbda):
         rolling_gamma = None  # the reference's fast path ignores it (functional.py:1101-1110)
     call = _prepare_td_lambda(gamma, lmbda, next_state_value, reward, done, terminated, rolling_gamma, time_dim, vec=True)
+    # the reference's vec variant returns promote(value dtype, dtype of a gamma / lmbda TENSOR), 0-dim ones included
+    # (its conv1d path multiplies the values by the coefficient tensors; the loop variant assigns into a value-dtype buffer)
+    out_dtype = next_state_value.dtype
+    for coef in (gamma, lmbda):
+        if isinstance(coef, torch.Tensor) and coef.dtype.is_floating_point:
+            out_dtype = torch.promote_types(out_dtype, coef.dtype)
     if _needs_grad(next_state_value, reward, gamma, lmbda):
         return _TdLambdaFunction.apply(next_state_value, reward, _coef_leaf(gamma, call.shape, time_dim),
-                                       _coef_leaf(lmbda, call.shape, time_dim), call, next_state_value.dtype,
+                                       _coef_leaf(lmbda, call.shape, time_dim), call, out_dtype,
                                        (gamma, lmbda, time_dim))
-    return _launch_td_lambda(call, next_state_value.dtype)
+    return _launch_td_lambda(call, out_dtype)
 
 
 def _check5(state_value, next_state_value, reward, done, terminated):
