@@ -139,6 +139,25 @@ int trl_gae_normalize_fwd(void *stream, int val_dtype, int coef_dtype,
                           double *stats, void *workspace, size_t workspace_bytes, int algo);
 
 /*
+ * trl_gae_normalize_fwd for callers that cannot allocate.  NO counterpart in the reference: it exists for callers that
+ * cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid allocation) and
+ * therefore have no workspace to pass.  Same arguments and results as trl_gae_normalize_fwd minus the workspace: the
+ * scratch is a file-scope device array inside the library, trl_static_scratch_bytes() (2 MiB) per GPU, held until the
+ * process ends.  Calls no hipMalloc / hipFree or any allocating routine.  Problems whose trl_workspace_bytes(O, T, I)
+ * exceeds the array are rejected with TRL_ERR_WORKSPACE.  Every call on a GPU shares that GPU's array (whatever the
+ * stream): calls that overlap in time on one GPU race -- order them on one stream or with events.
+ */
+size_t trl_static_scratch_bytes(void);
+int trl_gae_normalize_fwd_noalloc(void *stream, int val_dtype, int coef_dtype,
+                                  const void *reward, const void *state_value, const void *next_state_value,
+                                  const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                                  const void *gamma_t, const void *lg_t,
+                                  double gamma, double lmbda, double lg,
+                                  int64_t O, int64_t T, int64_t I,
+                                  void *advantage, void *value_target, double eps,
+                                  double *stats, int algo);
+
+/*
  * TD(lambda) return.
  * Replaces: td_lambda_return_estimate / vec_td_lambda_return_estimate
  *           (functional.py:783-889, 1030-1183).

@@ -48,6 +48,9 @@ _PROTOTYPES = {
                            _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _int]),
     "trl_gae_normalize_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _dbl,
                                      _i64, _i64, _i64, _vp, _vp, _dbl, _vp, _vp, _sz, _int]),
+    "trl_static_scratch_bytes": (_sz, []),
+    "trl_gae_normalize_fwd_noalloc": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _dbl,
+                                             _i64, _i64, _i64, _vp, _vp, _dbl, _vp, _int]),
     "trl_td_lambda_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _int,
                                  _i64, _i64, _i64, _vp, _vp, _sz, _int]),
     "trl_td1_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _int, _vp, _dbl, _int,

@@ -5,6 +5,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -453,6 +455,52 @@ int trl_gae_normalize_fwd(void *stream, int val_dtype, int coef_dtype, const voi
     return gae_normalize_impl(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated,
                               mask_bcast, gamma_t, lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, eps, stats, workspace,
                               workspace_bytes, nullptr, algo);
+}
+
+// ---- the entry point that allocates nothing -------------------------------------------------------------------------------
+// Callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid it) have no
+// workspace to pass: this variant of trl_gae_normalize_fwd brings its own, a file-scope device array.  Every GPU the library
+// runs on holds its own copy of the array (at its own address) until the process ends; the array's name is a host-side
+// stand-in, so host code only ever uses the per-device address hipGetSymbolAddress returned.
+constexpr size_t kStaticScratchBytes = 2u << 20;  // 2 MiB per GPU: C4 needs 0.33 MB, [1024 x 10000] (look-back records) 1.4 MB
+static __device__ __align__(256) unsigned char g_static_scratch[kStaticScratchBytes];  // zero-initialised at module load
+
+static void *static_scratch_ptr(int *err) {
+    static void *ptrs[64] = {nullptr};  // per device; written once
+    static std::mutex mu;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { *err = 1; return nullptr; }
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptrs[dev]) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch));  // the address on the CURRENT device
+        if (e != hipSuccess || !p) { *err = 2; return nullptr; }
+        ptrs[dev] = p;
+    }
+    *err = 0;
+    return ptrs[dev];
+}
+
+size_t trl_static_scratch_bytes(void) { return kStaticScratchBytes; }
+
+int trl_gae_normalize_fwd_noalloc(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
+                                  const void *next_state_value, const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                                  const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
+                                  int64_t O, int64_t T, int64_t I, void *advantage, void *value_target, double eps,
+                                  double *stats, int algo) {
+    if (int rc = check_dims("trl_gae_normalize_fwd_noalloc", O, T, I)) return rc;
+    const size_t need = trl_workspace_bytes(O, T, I);
+    if (need > kStaticScratchBytes)
+        return fail(TRL_ERR_WORKSPACE, "trl_gae_normalize_fwd_noalloc: a problem of (O, T, I) = (%lld, %lld, %lld) needs %zu bytes of "
+                    "scratch, the static scratch holds %zu; use trl_gae_normalize_fwd with a caller workspace",
+                    (long long)O, (long long)T, (long long)I, need, kStaticScratchBytes);
+    int err = 0;
+    void *ws = static_scratch_ptr(&err);
+    if (!ws) return fail(TRL_ERR_LAUNCH, err == 1 ? "trl_gae_normalize_fwd_noalloc: no current HIP device (or ordinal >= 64)"
+                                                  : "trl_gae_normalize_fwd_noalloc: hipGetSymbolAddress failed for the static scratch");
+    return gae_normalize_impl(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated,
+                              mask_bcast, gamma_t, lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, eps, stats, ws,
+                              kStaticScratchBytes, nullptr, algo);
 }
 
 int trl_gae_normalize_xchg_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
