@@ -67,6 +67,46 @@ void *lb_region(void *workspace, size_t workspace_bytes, i64 O, i64 T, i64 I, si
 
 }  // namespace
 
+// ---- host-visible failure flag of the single-launch (FUSED) path ----------------------------------------------------------
+// A fused launch whose persistent blocks were not co-resident gives up after a bounded wait, leaves the advantage
+// un-normalised and raises a word in pinned host memory; the next entry-point call on that GPU sees it WITHOUT
+// synchronising anything and fails with TRL_ERR_LAUNCH (then clears it): a training loop stops one step later instead of
+// training on bad advantages.  One word per device, allocated on the first fused launch (never by the no-alloc entry point).
+static unsigned *g_flag_host[64] = {nullptr};
+static unsigned *g_flag_dev[64] = {nullptr};
+static std::mutex g_flag_mu;
+
+static unsigned *fused_flag(bool may_allocate) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_flag_mu);
+    if (!g_flag_dev[dev] && may_allocate) {
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || !h) { (void)hipGetLastError(); return nullptr; }
+        *(volatile unsigned *)h = 0u;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) { (void)hipGetLastError(); (void)hipHostFree(h); return nullptr; }
+        g_flag_host[dev] = (unsigned *)h;
+        g_flag_dev[dev] = (unsigned *)d;
+    }
+    return g_flag_dev[dev];
+}
+
+// nonzero (and cleared) if a fused launch on the current device gave up since the last look
+static int take_fused_failure() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    volatile unsigned *h = g_flag_host[dev];
+    if (!h || *h == 0u) return 0;
+    *h = 0u;
+    return 1;
+}
+
+static int report_fused_failure(const char *fn) {
+    return fail(TRL_ERR_LAUNCH, "%s: an EARLIER single-launch GAE + normalise call on this GPU gave up waiting for its other blocks "
+                "(its persistent grid was not co-resident: another kernel held compute units); that call left the advantage "
+                "UN-NORMALISED.  Run the fused step alone on the GPU or pass TRL_ALGO_SCAN.", fn);
+}
+
 // Shifted value layout: next_state_value == NULL, state_value is the (O, T + 1, I) buffer (trl_value.h).
 // The wavefront-scan and fused kernels read it for I == 1; the SEQ kernels for any I.
 static int check_shifted(const char *fn, const void *next_state_value, int64_t I, int algo) {
@@ -116,6 +156,7 @@ static int gae_fwd_impl(void *stream, int val_dtype, int coef_dtype, const void 
                         int64_t O, int64_t T, int64_t I, void *advantage, void *value_target,
                         double *stats, void *workspace, size_t workspace_bytes, int algo, bool want_partials,
                         i64 *npartials_out) {
+    if (take_fused_failure()) return report_fused_failure("trl_gae_fwd");
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: bad dtype");
     if (int rc = check_dims("trl_gae_fwd", O, T, I)) return rc;
     if (!reward || !state_value || !done || !terminated || !advantage || !value_target)
@@ -284,6 +325,7 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype, const void *r
                       const uint8_t *done, const uint8_t *terminated, int mask_bcast, const void *gamma_t, const void *lmbda_t,
                       double gamma, double lmbda, int rolling_gamma, int64_t O, int64_t T, int64_t I,
                       void *returns, void *workspace, size_t workspace_bytes, int algo) {
+    if (take_fused_failure()) return report_fused_failure("trl_td_lambda_fwd");
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td_lambda_fwd: bad dtype");
     if (int rc = check_dims("trl_td_lambda_fwd", O, T, I)) return rc;
     if (!reward || !next_state_value || !done || !terminated || !returns)
@@ -319,6 +361,7 @@ int trl_td1_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward,
                 const uint8_t *done, const uint8_t *terminated, int mask_bcast, const void *gamma_t, double gamma,
                 int rolling_gamma, int64_t O, int64_t T, int64_t I, void *returns, void *workspace, size_t workspace_bytes,
                 int algo) {
+    if (take_fused_failure()) return report_fused_failure("trl_td1_fwd");
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td1_fwd: bad dtype");
     if (int rc = check_dims("trl_td1_fwd", O, T, I)) return rc;
     if (!reward || !next_state_value || !done || !terminated || !returns)
@@ -355,6 +398,7 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_
                    double rho_thresh, double c_thresh, const void *rho_thresh_t, const void *c_thresh_t,
                    int64_t O, int64_t T, int64_t I,
                    void *advantage, void *vs, void *workspace, size_t workspace_bytes, int algo) {
+    if (take_fused_failure()) return report_fused_failure("trl_vtrace_fwd");
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_fwd: bad dtype");
     if (int rc = check_dims("trl_vtrace_fwd", O, T, I)) return rc;
     if (!log_pi || !log_mu || !state_value || !reward || !done || !terminated || !advantage || !vs)
@@ -391,7 +435,9 @@ static int gae_normalize_impl(void *stream, int val_dtype, int coef_dtype, const
                               const void *next_state_value, const uint8_t *done, const uint8_t *terminated, int mask_bcast,
                               const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
                               int64_t O, int64_t T, int64_t I, void *advantage, void *value_target, double eps,
-                              double *stats, void *workspace, size_t workspace_bytes, void *comm, int algo) {
+                              double *stats, void *workspace, size_t workspace_bytes, void *comm, int algo,
+                              bool allocate_flag = true) {
+    if (take_fused_failure()) return report_fused_failure("trl_gae_normalize_fwd");
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_normalize_fwd: bad dtype");
     if (int rc = check_dims("trl_gae_normalize_fwd", O, T, I)) return rc;
     if (!reward || !state_value || !done || !terminated || !advantage || !value_target)
@@ -407,7 +453,7 @@ static int gae_normalize_impl(void *stream, int val_dtype, int coef_dtype, const
     if (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_FUSED) {
         GaeArgs a{reward, state_value, next_state_value, done, terminated, gamma_t, lg_t, gamma, lmbda, lg,
                   O, T, I, advantage, value_target, nullptr, 0};
-        LaunchResult res = launch_gae_fused(s, val_dtype, coef_dtype, a, eps, workspace, stats, comm);
+        LaunchResult res = launch_gae_fused(s, val_dtype, coef_dtype, a, eps, workspace, stats, comm, fused_flag(allocate_flag));
         if (res.status == 0) {
             if (int rc = check_launch("trl_gae_normalize_fwd(fused)")) return rc;
             g_kernel = comm ? "gae_fused_xchg" : res.kernel;
@@ -500,7 +546,7 @@ int trl_gae_normalize_fwd_noalloc(void *stream, int val_dtype, int coef_dtype, c
                                                   : "trl_gae_normalize_fwd_noalloc: hipGetSymbolAddress failed for the static scratch");
     return gae_normalize_impl(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated,
                               mask_bcast, gamma_t, lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, eps, stats, ws,
-                              kStaticScratchBytes, nullptr, algo);
+                              kStaticScratchBytes, nullptr, algo, /*allocate_flag=*/false);
 }
 
 int trl_gae_normalize_xchg_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
@@ -515,6 +561,7 @@ int trl_gae_normalize_xchg_fwd(void *stream, int val_dtype, int coef_dtype, cons
 }
 
 int trl_normalize(void *stream, int dtype, const void *x, int64_t n, const double *stats, double eps, void *out) {
+    if (take_fused_failure()) return report_fused_failure("trl_normalize");
     if (!dtype_ok(dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_normalize: bad dtype");
     if (n <= 0 || !x || !out || !stats) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_normalize: null pointer or n <= 0");
     launch_normalize((hipStream_t)stream, dtype, x, n, stats, eps, out);

@@ -200,4 +200,6 @@ int launch_normalize_from_partials(hipStream_t s, int dt, const void *x, i64 n, 
 // Fused single-launch GAE + normalisation (fused_kernels.hip).  status 2 = shape not eligible.
 constexpr size_t kFusedWsBytes = 256 + 4 * 512 * 128;  // header + 4 replicas of one 128-byte slot line per block, at the start of the workspace
 // comm: communicator of trl_xchg_open when the batch is sharded over GPUs (moments summed over ranks), else nullptr
-LaunchResult launch_gae_fused(hipStream_t s, int vdt, int cdt, const GaeArgs &a, double eps, void *ws, double *stats_out, void *comm);
+// host_flag: device view of a pinned host word the kernel raises when it gives up waiting (may be null)
+LaunchResult launch_gae_fused(hipStream_t s, int vdt, int cdt, const GaeArgs &a, double eps, void *ws, double *stats_out, void *comm,
+                              unsigned *host_flag);

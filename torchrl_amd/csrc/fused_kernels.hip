@@ -18,6 +18,9 @@
 //     them in a fixed order (bitwise reproducible) and broadcasts mean / std through LDS;
 //   * the normalised advantages are written: 22 B of HBM traffic per transition in total, the
 //     algorithmic minimum.
+//   * both outputs leave with WRITE-THROUGH 16-byte stores (sc1): nothing is left dirty in the L2s, so the
+//     end-of-kernel write-back is empty (launch-to-launch 8.6 -> 8.25 us at C4 against non-temporal stores, which
+//     stay dirty in L2; plain stores: 11.5 us).
 //
 // Workspace protocol: the first kFusedWsBytes of the workspace hold {epoch, error, slots[]}.
 // The caller zero-fills the workspace once; afterwards only this library touches it.  Each
@@ -25,7 +28,9 @@
 // has completed (every block has read the epoch by then).  All slots are rewritten by every
 // launch (the grid is always #CUs blocks), so a stale tag can never match.  Two launches that
 // share a workspace must not overlap (same stream, or external ordering).
-// Every spin is bounded (1 s wall clock): on timeout the error word is set and NaNs are written.
+// Every spin is bounded (1 s wall clock).  A launch that gives up (its blocks were not co-resident: something else
+// held CUs) writes the UN-NORMALISED advantage, sets the workspace's error word and raises the host-visible flag
+// (capi.hip: the next call on this GPU returns TRL_ERR_LAUNCH) -- never NaNs, never silently.
 #include "scan_core.h"
 #include "xchg.h"
 #include <cstdlib>
@@ -55,7 +60,7 @@ struct FusedGeom {
     i64 nchunks;
     double n_total;
     double eps;
-    int slot_stride;  // distance between two blocks' granule pairs, in 8-byte units
+    unsigned *host_flag;  // device view of the library's pinned host word (may be null): raised when a launch gives up
 };
 
 __device__ __forceinline__ unsigned long long tag_bits(double x, unsigned tag) {
@@ -63,22 +68,38 @@ __device__ __forceinline__ unsigned long long tag_bits(double x, unsigned tag) {
 }
 __device__ __forceinline__ double untag(unsigned long long b) { return __longlong_as_double((long long)(b & ~0xffull)); }
 
-// ABL (development only, tools/kbench): 0 = product; 1 = skip the gather (own block's moments);
-// 2 = also skip the block reduction; 3 = also skip the wave scan steps; 4 = last chunk's
-// value_target stored after the gather; 8 / 9 = value_target stored between publish and gather
-// (both slower than storing it at once); 10 = every chunk's loads issued up front.
-template <class Op, bool VEC, bool WAVE_INDEP, int K, int ABL = 0, int TEAMS = kTeams>
-__global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::Args args, FusedGeom geo, FusedWs *ws,
-                                                                  double *stats_out, xchg::Dev xd = xchg::Dev{nullptr, nullptr, 0, 1, 0}) {
+// 16-byte write-through store (global_store_dwordx4 sc1); other widths (ragged tails) as plain element stores.
+// The s_nop: a store of more than 64 bits reads its data registers one wait state after issue, and the compiler
+// does not know this asm is such a store (it may overwrite the registers with the very next instruction).
+template <bool VEC, typename T, int V>
+__device__ __forceinline__ void store_wt(T *__restrict__ p, i64 flat, int nvalid, const T (&in)[V]) {
+    if constexpr (VEC && V * sizeof(T) == 16) {
+        if (nvalid == V) {
+            u32x4 raw;
+            __builtin_memcpy(&raw, in, 16);
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p + flat), "v"(raw) : "memory");
+            return;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+        if (e < nvalid) p[flat + e] = in[e];
+}
+
+// FULL: every team's K chunks are complete (nchunks == K * grid * kTeams, whole chunks of 256*V elements, aligned):
+//       no clipping, every lane holds V valid elements -- the C4 shape class; 0.6 us per launch at [65536 x 32].
+// XCHG: the batch is sharded over GPUs; the moments are summed over the ranks inside the launch (xchg.h).
+template <class Op, bool VEC, bool WAVE_INDEP, int K, bool FULL, bool XCHG>
+__global__ __launch_bounds__(kFusedThreads) void gae_fused_kernel(typename Op::Args args, FusedGeom geo, FusedWs *ws, double *stats_out,
+                                                                  xchg::Dev xd) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
     constexpr int V = Op::V;
-    constexpr int NW = TEAMS * kTeam / kWave;
-    constexpr bool kDeferVt = ABL == 4;  // measured slower (9.6 vs 9.2 us): stores issued before the publish are free
-    constexpr bool kVtWindow = ABL == 8 || ABL == 9;  // all value_target stores between publish and gather
-    __shared__ TeamShared<Op> sh[TEAMS];
+    constexpr int NW = kFusedThreads / kWave;
+    static_assert(!FULL || VEC, "full chunks are vector-aligned");
+    __shared__ TeamShared<Op> sh[kTeams];
     __shared__ double red[2 * NW];
-    __shared__ double bc[3];
+    __shared__ TS bc_ms[2];
 
     const int team = threadIdx.x / kTeam;
     const int tid = threadIdx.x & (kTeam - 1);
@@ -87,47 +108,46 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
     const unsigned T = (unsigned)geo.T;
     const unsigned tag = (ws->epoch + 1u) & 0xffu;  // written by the previous launch: visible across the kernel boundary
     // batch sharded over GPUs: epoch of the cross-GPU mailbox, read before this block publishes
-    const unsigned xepoch = xd.local ? xd.local->epoch + 1u : 0u;
-    unsigned long long stamp0 = 0, stamp1 = 0, stamp2 = 0;
-    if constexpr (ABL == 7) stamp0 = wall_clock64();
+    unsigned xepoch = 0u;
+    if constexpr (XCHG) xepoch = xd.local->epoch + 1u;
 
     TS adv_keep[K][V];
-    TS vt_last[V];
-    TS vt_keep[kVtWindow ? K : 1][V];
     i64 flat_k[K];
     int nvalid_k[K];
 
-    auto chunk_of = [&](int k) { return ((i64)k * gridDim.x + blockIdx.x) * TEAMS + team; };
     auto geom_of = [&](int k, i64 &start, int &count) {
-        const i64 c = chunk_of(k);
-        const i64 row0 = c * geo.rows_per_chunk;
-        i64 nrows = c < geo.nchunks ? geo.O - row0 : 0;
-        if (nrows > geo.rows_per_chunk) nrows = geo.rows_per_chunk;
-        if (nrows < 0) nrows = 0;
-        start = row0 * geo.T;
-        count = (int)(nrows * geo.T);
+        const i64 c = ((i64)k * gridDim.x + blockIdx.x) * kTeams + team;
+        if constexpr (FULL) {
+            start = c * (i64)(kTeam * V);
+            count = kTeam * V;
+        } else {
+            const i64 row0 = c * geo.rows_per_chunk;
+            i64 nrows = c < geo.nchunks ? geo.O - row0 : 0;
+            if (nrows > geo.rows_per_chunk) nrows = geo.rows_per_chunk;
+            if (nrows < 0) nrows = 0;
+            start = row0 * geo.T;
+            count = (int)(nrows * geo.T);
+        }
     };
     auto nvalid_of = [&](int count) {
+        if constexpr (FULL) return V;
         int nv = count - lane_off;
         return nv < 0 ? 0 : (nv > V ? V : nv);
     };
 
     double s = 0.0, ss = 0.0;
-    constexpr bool kAllLoads = ABL == 10;  // every chunk's loads issued up front
-    constexpr int kRaw = kAllLoads ? K : 2;
-    typename Op::Raw raw[kRaw];
-#pragma unroll
-    for (int k = 0; k < (kAllLoads ? K : 1); ++k) {
+    typename Op::Raw raw[2];
+    {
         i64 start;
         int count;
-        geom_of(k, start, count);
-        load_inputs<Op, VEC>(args, start + lane_off, nvalid_of(count), raw[k]);
+        geom_of(0, start, count);
+        load_inputs<Op, VEC>(args, start + lane_off, nvalid_of(count), raw[0]);
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         i64 start;
         int count;
-        if (!kAllLoads && k + 1 < K) {
+        if (k + 1 < K) {
             geom_of(k + 1, start, count);
             load_inputs<Op, VEC>(args, start + lane_off, nvalid_of(count), raw[(k + 1) & 1]);
         }
@@ -137,76 +157,41 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
         flat_k[k] = flat;
         nvalid_k[k] = nvalid;
         Op op;
-        op.prepare(args, raw[kAllLoads ? k : (k & 1)]);
+        op.prepare(args, raw[k & 1]);
         TC Xc = (TC)0;
         TS Xv = (TS)0;
-        scan_chunk<Op, WAVE_INDEP>(op, sh[team], k & 1, nvalid, (unsigned)lane_off % T, T, (ABL == 3) ? 1 : geo.scan_lanes, Xc, Xv,
+        scan_chunk<Op, WAVE_INDEP>(op, sh[team], k & 1, nvalid, (unsigned)lane_off % T, T, geo.scan_lanes, Xc, Xv,
                                    [&](const TC(&xs)[V], const bool(&)[V], TC, TS) {
-                                       if constexpr (ABL == 5 || ABL == 6) {  // development: plain scan kernel shape
-                                           TS vt[V];
-                                           op.finish(nvalid, xs, adv_keep[k], vt, s, ss);
-                                           store_n<VEC>((TS *)args.value_target, flat, nvalid, vt);
-                                           store_n<VEC>((TS *)args.advantage, flat, nvalid, adv_keep[k]);
-                                       } else if constexpr (kVtWindow) {
-                                           op.finish(nvalid, xs, adv_keep[k], vt_keep[k], s, ss);
-                                       } else if (kDeferVt && k == K - 1) {
-                                           // the last chunk's value_target is stored after the gather: the
-                                           // memory pipes are quiet while the moments are exchanged
-                                           op.finish(nvalid, xs, adv_keep[k], vt_last, s, ss);
-                                       } else {
-                                           TS vt[V];
-                                           op.finish(nvalid, xs, adv_keep[k], vt, s, ss);
-                                           store_n<VEC>((TS *)args.value_target, flat, nvalid, vt);
-                                       }
+                                       TS vt[V];
+                                       op.finish(nvalid, xs, adv_keep[k], vt, s, ss);
+                                       store_wt<VEC>((TS *)args.value_target, flat, nvalid, vt);
                                    });
     }
 
-    if constexpr (ABL == 5) return;
-    if constexpr (ABL == 6) {  // development: + per-block partials, as the unfused SCAN kernel writes them
-        s = wave_sum(s);
-        ss = wave_sum(ss);
-        if (lane == 0) { red[2 * wv] = s; red[2 * wv + 1] = ss; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double bs = 0.0, bss = 0.0;
-            for (int k = 0; k < NW; ++k) { bs += red[2 * k]; bss += red[2 * k + 1]; }
-            stats_out[2 * blockIdx.x] = bs;
-            stats_out[2 * blockIdx.x + 1] = bss;
-        }
-        return;
-    }
     // ---- block moments -> publish -> gather everybody's --------------------------------------------
-    if constexpr (ABL == 0 || ABL == 1 || ABL == 4 || ABL >= 7) {
-        s = wave_sum(s);
-        ss = wave_sum(ss);
-        if (lane == 0) {
-            red[2 * wv] = s;
-            red[2 * wv + 1] = ss;
-        }
-        __syncthreads();
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (lane == 0) {
+        red[2 * wv] = s;
+        red[2 * wv + 1] = ss;
     }
-    if constexpr (ABL >= 1 && ABL <= 3) {
-        if (threadIdx.x == 0) { bc[0] = geo.n_total; bc[1] = s * gridDim.x; bc[2] = ss * gridDim.x + 1.0; }
-    } else if (wv == 0) {
+    __syncthreads();
+    if (wv == 0) {
         double bs = 0.0, bss = 0.0;  // every lane of wave 0 forms the block totals in the same fixed order
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
             bs += red[2 * k];
             bss += red[2 * k + 1];
         }
-        if constexpr (ABL == 7) stamp1 = wall_clock64();
+        __builtin_amdgcn_s_setprio(3);  // the publish and the polls go ahead of the other waves' traffic (8.25 -> 8.18 us)
         // kSlotReplicas copies of every block's granules (lane r writes copy r): the blocks that poll one line drop
         // from #blocks to #blocks / kSlotReplicas (9.25 -> 9.12 us at C4; 2 / 4 / 8 copies measured, 4 is enough)
         constexpr int kRep = kSlotReplicas;
-        const size_t rep_off = (size_t)(blockIdx.x % kRep) * gridDim.x * geo.slot_stride;
+        const size_t rep_off = (size_t)(blockIdx.x % kRep) * gridDim.x * kSlotStride;
         if (lane < kRep) {
-            unsigned long long *sl = ws->slots + ((size_t)lane * gridDim.x + blockIdx.x) * geo.slot_stride;
+            unsigned long long *sl = ws->slots + ((size_t)lane * gridDim.x + blockIdx.x) * kSlotStride;
             __hip_atomic_store(sl, tag_bits(bs, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(sl + 1, tag_bits(bss, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if constexpr (ABL == 8) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) store_n<VEC>((TS *)args.value_target, flat_k[k], nvalid_k[k], vt_keep[k]);
         }
         // lane l gathers blocks l, l+64, ...: only the granules still missing are re-polled
         constexpr int kPer = kMaxBlocks / kWave;
@@ -221,7 +206,7 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
 #pragma unroll
             for (int j = 0; j < kPer; ++j) {
                 if (!got[j]) {
-                    const unsigned long long *sl = ws->slots + rep_off + (size_t)(lane + kWave * j) * geo.slot_stride;
+                    const unsigned long long *sl = ws->slots + rep_off + (size_t)(lane + kWave * j) * kSlotStride;
                     vs[j] = __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     vq[j] = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -233,11 +218,11 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
             }
             if (__all(ok)) break;
             if (wall_clock64() - t_start > 100000000ull) break;  // 1 s at 100 MHz: give up loudly
-            __builtin_amdgcn_s_sleep(1);  // sleep 0 / 4 / 10: no gain; two or three poll rounds in flight (also of the missing
-                                          // granules only): 16 - 23 us -- extra polls slow the publishes down
+            // no sleep between rounds (sleep 1 / 4: +0.03 / +0.1 us); two or three poll rounds in flight (also of the
+            // missing granules only): 16 - 23 us -- extra polls slow the publishes down
         }
+        __builtin_amdgcn_s_setprio(0);
         const bool all_ok = __all(ok);
-        if constexpr (ABL == 7) stamp2 = wall_clock64();
         double acc = 0.0, acq = 0.0;
 #pragma unroll
         for (int j = 0; j < kPer; ++j)
@@ -246,48 +231,46 @@ __global__ __launch_bounds__(TEAMS * kTeam) void gae_fused_kernel(typename Op::A
         double tot_ss = wave_sum(acq);
         double tot_n = geo.n_total;
         bool x_ok = true;
-        if (xd.local) {
+        if constexpr (XCHG) {
             // second stage, across GPUs: block 0 stores this GPU's totals into every peer's mailbox over
-            // xGMI; every block then polls the LOCAL mailbox for all ranks' totals (xchg.h)
-            if (blockIdx.x == 0) xchg::send(xd, xepoch, lane, tot_n, acc, tot_ss);
+            // xGMI; every block then polls the LOCAL mailbox for all ranks' totals (xchg.h).  A rank whose own gather
+            // gave up sends NaN, so that every rank sees the failure.
+            const double nan = __longlong_as_double(0x7ff8000000000000LL);
+            if (blockIdx.x == 0) xchg::send(xd, xepoch, lane, tot_n, all_ok ? acc : nan, all_ok ? tot_ss : nan);
             x_ok = xchg::recv_sum(xd, xepoch, lane, tot_n, acc, tot_ss);
+            x_ok = x_ok && acc == acc && tot_ss == tot_ss;
         }
         if (lane == 0) {
-            const double nan = __longlong_as_double(0x7ff8000000000000LL);
             const bool good = all_ok && x_ok;
-            bc[0] = tot_n;
-            bc[1] = good ? acc : nan;
-            bc[2] = good ? tot_ss : nan;
-            if (!all_ok) ws->error = 1u;
-            if (!x_ok) xd.local->error = 1u;
+            TS mean_s = (TS)0, std_s = (TS)1;  // a launch that gave up leaves the advantage un-normalised
+            if (good) mean_std<TS>(tot_n, acc, tot_ss, geo.eps, mean_s, std_s);
+            bc_ms[0] = mean_s;
+            bc_ms[1] = std_s;
+            if (!good) {
+                if (!all_ok) ws->error = 1u;
+                if constexpr (XCHG) { if (!x_ok) xd.local->error = 1u; }
+                if (geo.host_flag) __hip_atomic_store(geo.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             if (blockIdx.x == 0) {
                 ws->epoch = ws->epoch + 1u;  // every block has read the old epoch: all of them have published
-                if (xd.local) xd.local->epoch = xepoch;  // likewise: every block read it before publishing
-                if (stats_out && ABL != 7) {
+                if constexpr (XCHG) xd.local->epoch = xepoch;  // likewise: every block read it before publishing
+                if (stats_out) {
+                    const double nan = __longlong_as_double(0x7ff8000000000000LL);
                     stats_out[0] = tot_n;
-                    stats_out[1] = bc[1];
-                    stats_out[2] = bc[2];
+                    stats_out[1] = good ? acc : nan;
+                    stats_out[2] = good ? tot_ss : nan;
                 }
             }
         }
     }
     __syncthreads();
-    TS mean_s, std_s;
-    mean_std<TS>(bc[0], bc[1], bc[2], geo.eps, mean_s, std_s);
+    const TS mean_s = bc_ms[0], std_s = bc_ms[1];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         TS out[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) out[e] = (adv_keep[k][e] - mean_s) / std_s;
-        store_n<VEC>((TS *)args.advantage, flat_k[k], nvalid_k[k], out);
-    }
-    if constexpr (kDeferVt && !kVtWindow) store_n<VEC>((TS *)args.value_target, flat_k[K - 1], nvalid_k[K - 1], vt_last);
-    if constexpr (ABL == 7) {
-        if (threadIdx.x == 0) {
-            unsigned long long *dbg = (unsigned long long *)stats_out + 4 * blockIdx.x;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            dbg[0] = stamp0; dbg[1] = stamp1; dbg[2] = stamp2; dbg[3] = wall_clock64();
-        }
+        store_wt<VEC>((TS *)args.advantage, flat_k[k], nvalid_k[k], out);
     }
 }
 
@@ -306,8 +289,29 @@ int device_cus() {
     return cached[dev];
 }
 
+// The persistent grid needs one resident block per CU: ask the runtime once per kernel whether a 1024-thread block of
+// this instantiation fits a CU at all (registers / LDS).  Whether the CUs are FREE at launch time cannot be asked: a GPU
+// that runs other long kernels beside this one starves the gather (bounded wait -> error flag, un-normalised output).
+template <class KernelT>
+bool fused_block_fits(KernelT kernel) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kFusedThreads, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return nb >= 1;
+}
+
+template <class Op, bool VEC, bool WI, int K, bool FULL, bool XCHG>
+int launch_fused_inst(hipStream_t s, const dim3 grid, const GaeArgs &a, const FusedGeom &geo, FusedWs *w, double *stats_out,
+                      const xchg::Dev &xd) {
+    auto kernel = gae_fused_kernel<Op, VEC, WI, K, FULL, XCHG>;
+    static const bool fits = fused_block_fits(kernel);
+    if (!fits) return 2;
+    hipLaunchKernelGGL(kernel, grid, dim3(kFusedThreads), 0, s, a, geo, w, stats_out, xd);
+    return 0;
+}
+
 template <class Op>
-LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *ws, double *stats_out, const xchg::Dev &xd) {
+LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *ws, double *stats_out, const xchg::Dev &xd,
+                            unsigned *host_flag) {
     constexpr int V = Op::V;
     const i64 chunk = (i64)kTeam * V;
     if (a.I != 1 || a.T > chunk) return LaunchResult{2, 0, nullptr};
@@ -334,37 +338,47 @@ LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *w
                     aligned16(a.value_target);
     const bool vec = al && (nchunks == 1 || (R * a.T) % V == 0);
     const bool wi = ((i64)kWave * V) % a.T == 0;
-    FusedGeom geo{a.O, a.T, (int)R, scan_lanes_for(a.T, V, wi), nchunks, (double)a.O * (double)a.T, eps, kSlotStride};
-    const dim3 grid((unsigned)G), block(kFusedThreads);
+    const int KK = k_needed <= 2 ? 2 : k_needed <= 4 ? 4 : 8;
+    // every team's KK chunks complete: whole chunks (R*T == 256*V), all rows used, exactly KK chunks per team
+    const bool full = vec && R * a.T == chunk && a.O % R == 0 && nchunks == (i64)KK * per_iter;
+    FusedGeom geo{a.O, a.T, (int)R, scan_lanes_for(a.T, V, wi), nchunks, (double)a.O * (double)a.T, eps, host_flag};
+    const dim3 grid((unsigned)G);
     FusedWs *w = (FusedWs *)ws;
-#define TRL_FUSED(VEC, WI, KK) hipLaunchKernelGGL((gae_fused_kernel<Op, VEC, WI, KK>), grid, block, 0, s, a, geo, w, stats_out, xd)
-#define TRL_FUSED_K(VEC, WI)                                     \
-    do {                                                         \
-        if (k_needed <= 2) TRL_FUSED(VEC, WI, 2);                \
-        else if (k_needed <= 4) TRL_FUSED(VEC, WI, 4);           \
-        else if constexpr (!kMixed) TRL_FUSED(VEC, WI, 8);       \
+    const bool x = xd.local != nullptr;
+    int rc = 2;
+#define TRL_FUSED(VEC, WI, KK_, FULL_, X_) rc = launch_fused_inst<Op, VEC, WI, KK_, FULL_, X_>(s, grid, a, geo, w, stats_out, xd)
+#define TRL_FUSED_X(VEC, WI, KK_, FULL_) do { if (x) TRL_FUSED(VEC, WI, KK_, FULL_, true); else TRL_FUSED(VEC, WI, KK_, FULL_, false); } while (0)
+#define TRL_FUSED_K(VEC, WI, FULL_)                                        \
+    do {                                                                   \
+        if (KK == 2) TRL_FUSED_X(VEC, WI, 2, FULL_);                       \
+        else if (KK == 4) TRL_FUSED_X(VEC, WI, 4, FULL_);                  \
+        else if constexpr (!kMixed) TRL_FUSED_X(VEC, WI, 8, FULL_);        \
     } while (0)
-    if (vec) { if (wi) TRL_FUSED_K(true, true); else TRL_FUSED_K(true, false); }
-    else     { if (wi) TRL_FUSED_K(false, true); else TRL_FUSED_K(false, false); }
+    if (full) { if (wi) TRL_FUSED_K(true, true, true); else TRL_FUSED_K(true, false, true); }
+    else if (vec) { if (wi) TRL_FUSED_K(true, true, false); else TRL_FUSED_K(true, false, false); }
+    else { if (wi) TRL_FUSED_K(false, true, false); else TRL_FUSED_K(false, false, false); }
 #undef TRL_FUSED_K
+#undef TRL_FUSED_X
 #undef TRL_FUSED
+    if (rc != 0) return LaunchResult{rc, 0, nullptr};
     return LaunchResult{0, 0, "gae_fused"};
 }
 
 }  // namespace
 
-LaunchResult launch_gae_fused(hipStream_t s, int vdt, int cdt, const GaeArgs &a, double eps, void *ws, double *stats_out, void *comm) {
+LaunchResult launch_gae_fused(hipStream_t s, int vdt, int cdt, const GaeArgs &a, double eps, void *ws, double *stats_out, void *comm,
+                              unsigned *host_flag) {
     const xchg::Dev xd = xchg_dev_of(comm);
     if (!a.next_value) {  // shifted value layout: its own instantiations (scan_core.h: Shifted<>)
-        if (vdt == 0 && cdt == 0) return launch_fused_t<GaeShiftedOp<float, float, 4>>(s, a, eps, ws, stats_out, xd);
-        if (vdt == 1 && cdt == 1) return launch_fused_t<GaeShiftedOp<double, double, 2>>(s, a, eps, ws, stats_out, xd);
-        if (vdt == 1 && cdt == 0) return launch_fused_t<GaeShiftedOp<double, float, 2>>(s, a, eps, ws, stats_out, xd);
-        if (vdt == 0 && cdt == 1) return launch_fused_t<GaeShiftedOp<float, double, 4>>(s, a, eps, ws, stats_out, xd);
+        if (vdt == 0 && cdt == 0) return launch_fused_t<GaeShiftedOp<float, float, 4>>(s, a, eps, ws, stats_out, xd, host_flag);
+        if (vdt == 1 && cdt == 1) return launch_fused_t<GaeShiftedOp<double, double, 2>>(s, a, eps, ws, stats_out, xd, host_flag);
+        if (vdt == 1 && cdt == 0) return launch_fused_t<GaeShiftedOp<double, float, 2>>(s, a, eps, ws, stats_out, xd, host_flag);
+        if (vdt == 0 && cdt == 1) return launch_fused_t<GaeShiftedOp<float, double, 4>>(s, a, eps, ws, stats_out, xd, host_flag);
         return LaunchResult{1, 0, nullptr};
     }
-    if (vdt == 0 && cdt == 0) return launch_fused_t<GaeOp<float, float, 4>>(s, a, eps, ws, stats_out, xd);
-    if (vdt == 1 && cdt == 1) return launch_fused_t<GaeOp<double, double, 2>>(s, a, eps, ws, stats_out, xd);
-    if (vdt == 1 && cdt == 0) return launch_fused_t<GaeOp<double, float, 2>>(s, a, eps, ws, stats_out, xd);
-    if (vdt == 0 && cdt == 1) return launch_fused_t<GaeOp<float, double, 4>>(s, a, eps, ws, stats_out, xd);
+    if (vdt == 0 && cdt == 0) return launch_fused_t<GaeOp<float, float, 4>>(s, a, eps, ws, stats_out, xd, host_flag);
+    if (vdt == 1 && cdt == 1) return launch_fused_t<GaeOp<double, double, 2>>(s, a, eps, ws, stats_out, xd, host_flag);
+    if (vdt == 1 && cdt == 0) return launch_fused_t<GaeOp<double, float, 2>>(s, a, eps, ws, stats_out, xd, host_flag);
+    if (vdt == 0 && cdt == 1) return launch_fused_t<GaeOp<float, double, 4>>(s, a, eps, ws, stats_out, xd, host_flag);
     return LaunchResult{1, 0, nullptr};
 }

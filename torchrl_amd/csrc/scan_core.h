@@ -56,7 +56,11 @@ template <typename T, int V>
 __device__ __forceinline__ void vload(const T *__restrict__ p, T (&out)[V]) {
     constexpr int B = V * (int)sizeof(T);
     if constexpr (B <= 16) {
+#ifdef TRL_NT_LOADS  // development switch (tools/kbench): non-temporal input loads
+        typename RawT<B>::type raw = __builtin_nontemporal_load((const typename RawT<B>::type *)p);
+#else
         typename RawT<B>::type raw = *(const typename RawT<B>::type *)p;
+#endif
         __builtin_memcpy(out, &raw, B);
     } else {
         static_assert(B % 16 == 0, "vector width");
