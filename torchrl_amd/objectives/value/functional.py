@@ -490,6 +490,23 @@ def _next_in_time(x3, last):
     return torch.cat([x3[:, 1:], last.expand_as(x3[:, :1])], 1)
 
 
+def _gae_bwd(c, g_adv, g_vt, need_v: bool, need_nv: bool, need_r: bool):
+    """(d_state_value, d_next_state_value, d_reward) of GAE through trl_gae_bwd (None where not needed)."""
+    lib = _extension.get_lib()
+    dev = c.reward.device
+    ga, gv = _grad_in(g_adv, c, c.vdt), _grad_in(g_vt, c, c.vdt)
+    new = lambda on: torch.empty(c.shape, dtype=c.vdt, device=dev) if on else None
+    d_v, d_nv, d_r = new(need_v), new(need_nv), new(need_r)
+    if d_v is not None or d_nv is not None or d_r is not None:
+        wsp, wsb, _ws = _bwd_ws(lib, c)
+        with _on(dev):
+            rc = lib.trl_gae_bwd(_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(ga), _ptr(gv), _ptr(c.done), _ptr(c.terminated),
+                                 c.mask_bcast, _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg, c.O, c.T, c.I,
+                                 _ptr(d_r), _ptr(d_v), _ptr(d_nv), wsp, wsb, _BWD_ALGO)
+        _bwd_done(rc, lib)
+    return d_v, d_nv, d_r
+
+
 class _GaeFunction(torch.autograd.Function):
     """``coefs = (gamma, lmbda, time_dim)`` as the caller passed them; ``gamma_e`` / ``lmbda_e`` are their
     differentiable full-shape views (:func:`_coef_leaf`) or None."""
@@ -517,19 +534,9 @@ class _GaeFunction(torch.autograd.Function):
         none5 = (None, None, None, None, None)
         if g_adv is None and g_vt is None:
             return (None, None, None) + none5
-        lib = _extension.get_lib()
         dev = c.reward.device
-        ga, gv = _grad_in(g_adv, c, c.vdt), _grad_in(g_vt, c, c.vdt)
         need = ctx.needs_input_grad
-        new = lambda on: torch.empty(c.shape, dtype=c.vdt, device=dev) if on else None
-        d_v, d_nv, d_r = new(need[0]), new(need[1]), new(need[2] or want_coef)
-        if d_v is not None or d_nv is not None or d_r is not None:
-            wsp, wsb, _ws = _bwd_ws(lib, c)
-            with _on(dev):
-                rc = lib.trl_gae_bwd(_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(ga), _ptr(gv), _ptr(c.done), _ptr(c.terminated),
-                                     c.mask_bcast, _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg, c.O, c.T, c.I,
-                                     _ptr(d_r), _ptr(d_v), _ptr(d_nv), wsp, wsb, _BWD_ALGO)
-            _bwd_done(rc, lib)
+        d_v, d_nv, d_r = _gae_bwd(c, g_adv, g_vt, need[0], need[1], need[2] or want_coef)
         d_gamma = d_lmbda = None
         if want_coef:
             # A_t = delta_t + (lmbda_t gamma_t (1 - done_t)) A_{t+1},  delta_t = r_t + gamma_t (1 - terminated_t) v'_t - v_t
@@ -658,6 +665,30 @@ class _Td1Function(torch.autograd.Function):
         return outs + (d_gamma, None, None)
 
 
+def _vtrace_bwd(c, g_adv, g_vs, vs, need, need_gamma: bool):
+    """Gradients w.r.t. (log_pi, log_mu, state_value, next_state_value, reward) -- None where ``need`` is False -- and the
+    per-element gamma gradient (or None), through ONE launch of trl_vtrace_bwd."""
+    lib = _extension.get_lib()
+    dev = c.reward.device
+    odt = torch.promote_types(c.vdt, c.cdt)
+    ga, gs = _grad_in(g_adv, c, odt), _grad_in(g_vs, c, odt)
+    new = lambda on, dt=c.vdt: torch.empty(c.shape, dtype=dt, device=dev) if on else None
+    outs = [new(n) for n in need]
+    d_gamma_t = new(need_gamma, odt)
+    vs = vs.detach()
+    if vs.dtype != odt:
+        vs = vs.to(odt)
+    vs = vs.contiguous()
+    wsp, wsb, _ws = _bwd_ws(lib, c)
+    with _on(dev):
+        rc = lib.trl_vtrace_bwd(_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(ga), _ptr(gs), _ptr(c.log_pi), _ptr(c.log_mu),
+                                _ptr(c.value), _ptr(c.next_value), _ptr(c.reward), _ptr(vs), _ptr(c.done),
+                                _ptr(c.terminated), c.mask_bcast, _ptr(c.gamma_t), c.gamma, c.rho_thresh, c.c_thresh,
+                                _ptr(c.rho_t), _ptr(c.c_t), c.O, c.T, c.I, *(_ptr(o) for o in outs), _ptr(d_gamma_t), wsp, wsb, _BWD_ALGO)
+    _bwd_done(rc, lib)
+    return outs, d_gamma_t
+
+
 class _VtraceFunction(torch.autograd.Function):
     """V-trace with gradients to log_pi / log_mu / state_value / next_state_value / reward (and a gamma tensor).
     Forward on trl_vtrace_fwd; backward = ONE launch of trl_vtrace_bwd."""
@@ -677,23 +708,83 @@ class _VtraceFunction(torch.autograd.Function):
         if g_adv is None and g_vs is None:
             return (None,) * 7
         (vs,) = ctx.saved_tensors
-        lib = _extension.get_lib()
-        dev = c.reward.device
-        odt = torch.promote_types(c.vdt, c.cdt)
-        ga, gs = _grad_in(g_adv, c, odt), _grad_in(g_vs, c, odt)
         need = ctx.needs_input_grad
-        new = lambda on, dt=c.vdt: torch.empty(c.shape, dtype=dt, device=dev) if on else None
-        outs = [new(n) for n in need[:5]]
-        d_gamma_t = new(ctx.gamma_e is not None, odt)
-        wsp, wsb, _ws = _bwd_ws(lib, c)
-        with _on(dev):
-            rc = lib.trl_vtrace_bwd(_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(ga), _ptr(gs), _ptr(c.log_pi), _ptr(c.log_mu),
-                                    _ptr(c.value), _ptr(c.next_value), _ptr(c.reward), _ptr(vs.contiguous()), _ptr(c.done),
-                                    _ptr(c.terminated), c.mask_bcast, _ptr(c.gamma_t), c.gamma, c.rho_thresh, c.c_thresh,
-                                    _ptr(c.rho_t), _ptr(c.c_t), c.O, c.T, c.I, *(_ptr(o) for o in outs), _ptr(d_gamma_t), wsp, wsb, _BWD_ALGO)
-        _bwd_done(rc, lib)
+        outs, d_gamma_t = _vtrace_bwd(c, g_adv, g_vs, vs, need[:5], ctx.gamma_e is not None)
         res = tuple(None if o is None else o.to(d).view(s) for o, (d, s) in zip(outs, ctx.ins))
         return res + (_coef_grad(d_gamma_t, ctx.gamma_e, c) if d_gamma_t is not None else None, None)
+
+
+# ---------------------------------------------------------------------------------------------
+# GAE fast path: the common call (python-float gamma / lmbda, contiguous same-dtype tensors on the current
+# device, time at dim -2, no autograd) goes from the public signature to ONE ctypes call without building the
+# general call description -- the general path costs 2 - 4x the kernel at the small BASELINE shapes.  Anything
+# else (and every error) falls through to the general path, which validates and raises as the reference does.
+# ---------------------------------------------------------------------------------------------
+_FAST_COEF = {}   # (gamma, lmbda, default dtype) -> (gamma rounded, lmbda*gamma rounded, coefficient dtype code)
+_FAST_NEED = {}   # (O, T, I) -> trl_workspace_bytes
+_T32, _T64, _TBOOL = torch.float32, torch.float64, torch.bool
+
+
+def _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, terminated, eps, algo=ALGO_AUTO):
+    """``(advantage, value_target)`` through the fast path (``eps`` not None: normalised advantage), or None."""
+    if type(gamma) is not float or type(lmbda) is not float:
+        return None
+    if terminated is None:
+        terminated = done
+    nsv = next_state_value
+    shape = nsv.shape
+    if len(shape) < 2 or not (state_value.shape == shape == reward.shape == done.shape == terminated.shape):
+        return None
+    dt = nsv.dtype
+    if (dt is not _T32 and dt is not _T64) or state_value.dtype is not dt or reward.dtype is not dt \
+            or done.dtype is not _TBOOL or terminated.dtype is not _TBOOL:
+        return None
+    dev = nsv.device
+    if dev.type != "cuda" or dev.index != torch.cuda.current_device() or state_value.device != dev or reward.device != dev \
+            or done.device != dev or terminated.device != dev:
+        return None
+    if not (nsv.is_contiguous() and state_value.is_contiguous() and reward.is_contiguous() and done.is_contiguous()
+            and terminated.is_contiguous()):
+        return None
+    if torch.is_grad_enabled() and (nsv.requires_grad or state_value.requires_grad or reward.requires_grad):
+        return None
+    n = nsv.numel()
+    if n == 0:
+        return None
+    key = (gamma, lmbda, torch.get_default_dtype())
+    coef = _FAST_COEF.get(key)
+    if coef is None:
+        g_val, g_dt = _scalar_mask_coef(gamma)
+        lg_val, lg_dt = _scalar_mask_coef(lmbda * gamma)
+        cdt = torch.promote_types(g_dt, lg_dt)
+        if cdt not in _DT:
+            return None
+        coef = _FAST_COEF[key] = (g_val, lg_val, _DT[cdt])
+    T, I = shape[-2], shape[-1]
+    O = n // (T * I)
+    lib = _extension.get_lib()
+    stream = torch._C._cuda_getCurrentRawStream(dev.index)
+    adv, vt = torch.empty_like(nsv), torch.empty_like(nsv)
+    if eps is None:
+        ws = _lookback_workspace(lib, dev, O, T, I) if (I == 1 and T >= 2048 and O < 4096) else None
+        rc = lib.trl_gae_fwd(stream, _DT[dt], coef[2], reward.data_ptr(), state_value.data_ptr(), nsv.data_ptr(),
+                             done.data_ptr(), terminated.data_ptr(), 0, None, None, coef[0], 0.0, coef[1], O, T, I,
+                             adv.data_ptr(), vt.data_ptr(), None, None if ws is None else ws.data_ptr(),
+                             0 if ws is None else ws.numel(), algo)
+    else:
+        okey = (O, T, I)
+        need = _FAST_NEED.get(okey)
+        if need is None:
+            need = _FAST_NEED[okey] = lib.trl_workspace_bytes(O, T, I)
+        ws = _WORKSPACES.get((dev.index, stream))
+        if ws is None or ws.numel() < need:
+            ws = _workspace(lib, dev, O, T, I)
+        rc = lib.trl_gae_normalize_fwd(stream, _DT[dt], coef[2], reward.data_ptr(), state_value.data_ptr(), nsv.data_ptr(),
+                                       done.data_ptr(), terminated.data_ptr(), 0, None, None, coef[0], 0.0, coef[1], O, T, I,
+                                       adv.data_ptr(), vt.data_ptr(), eps, None, ws.data_ptr(), ws.numel(), algo)
+    if rc:
+        _extension.check(rc, lib)
+    return adv, vt
 
 
 def _geom_series_like(t: torch.Tensor, r, thr: float) -> torch.Tensor:
@@ -727,6 +818,14 @@ def generalized_advantage_estimate(
     Returns ``(advantage, value_target)``.  All tensors must have shape
     ``[*Batch x TimeSteps x *F]``; ``terminated`` defaults to ``done``.
     """
+    if torch.compiler.is_compiling():
+        (g, gt), (l, lt) = _ops._split(gamma), _ops._split(lmbda)
+        return _ops.gae_op(state_value, next_state_value, reward, done, done if terminated is None else terminated, g, l, gt, lt,
+                           time_dim, False)
+    if time_dim == -2:
+        out = _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, terminated, None)
+        if out is not None:
+            return out
     call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
     if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
         return _GaeFunction.apply(state_value, next_state_value, reward, _coef_leaf(gamma, call.shape, time_dim),
@@ -748,6 +847,14 @@ def vec_generalized_advantage_estimate(
 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Vectorized GAE (reference: functional.py:272-370).  Same kernels as the loop variant:
     the result is exact rather than filter-truncated."""
+    if torch.compiler.is_compiling():
+        (g, gt), (l, lt) = _ops._split(gamma), _ops._split(lmbda)
+        return _ops.gae_op(state_value, next_state_value, reward, done, done if terminated is None else terminated, g, l, gt, lt,
+                           time_dim, True)
+    if time_dim == -2:
+        out = _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, terminated, None)
+        if out is not None:
+            return out
     call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
     call.out_dtype = state_value.dtype  # functional.py:314
     if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
@@ -831,6 +938,16 @@ def gae_normalized(gamma, lmbda, state_value, next_state_value, reward, done, te
     scale pass, so every rank normalises with the global statistics.  ``exchange``
     (:class:`StatsExchange`, intra-node): the moments cross the GPUs inside the launch instead
     (peer-to-peer mailbox stores over xGMI) and the sharded step stays one launch per GPU."""
+    if torch.compiler.is_compiling():
+        if exchange is not None or group is not None or distributed or algo != ALGO_AUTO:
+            raise NotImplementedError("gae_normalized under torch.compile: single-GPU call only")
+        (g, gt), (l, lt) = _ops._split(gamma), _ops._split(lmbda)
+        return _ops.gae_normalized_op(state_value, next_state_value, reward, done, done if terminated is None else terminated, g, l,
+                                      gt, lt, float(eps), time_dim)
+    if time_dim == -2 and exchange is None and group is None and not distributed:
+        out = _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, terminated, float(eps), algo)
+        if out is not None:
+            return out
     call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
     if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
         # differentiable path: GAE through the autograd function, normalisation as the reference's torch ops
@@ -908,6 +1025,8 @@ def standardize(x: torch.Tensor, eps: float, group=None, distributed: bool = Fal
     """Out-of-place ``(x - mean) / std.clamp_min(eps)`` over all elements.  With ``distributed``
     (or an explicit process ``group``) the fp64 moments are all-reduced first -- one 24-byte RCCL
     all-reduce -- so every rank normalises with the global statistics of the sharded batch."""
+    if torch.compiler.is_compiling() and not distributed and group is None:
+        return _ops.standardize_op(x, float(eps))
     xc = x.detach().contiguous()
     if (distributed or group is not None) and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
         st = moments(xc)
@@ -1037,6 +1156,10 @@ def td_lambda_return_estimate(
     ``rolling_gamma=False`` (each return uses the gamma / lmbda of its own first step for the
     whole tail) runs the O(T^2) kernel and needs a gamma or lmbda tensor.
     """
+    if torch.compiler.is_compiling():
+        (g, gt), (l, lt) = _ops._split(gamma), _ops._split(lmbda)
+        return _ops.td_lambda_op(next_state_value, reward, done, done if terminated is None else terminated, g, l, gt, lt,
+                                 -1 if rolling_gamma is None else int(bool(rolling_gamma)), time_dim, False)
     call = _prepare_td_lambda(gamma, lmbda, next_state_value, reward, done, terminated, rolling_gamma, time_dim)
     if _needs_grad(next_state_value, reward, gamma, lmbda):
         return _TdLambdaFunction.apply(next_state_value, reward, _coef_leaf(gamma, call.shape, time_dim),
@@ -1059,6 +1182,10 @@ def vec_td_lambda_return_estimate(
     r"""Vectorized TD(:math:`\lambda`) return estimate (reference: functional.py:1030-1183).
     Same kernels as the loop variant; keeps the reference's ``NotImplementedError`` for
     ``rolling_gamma=False`` with tensor coefficients."""
+    if torch.compiler.is_compiling():
+        (g, gt), (l, lt) = _ops._split(gamma), _ops._split(lmbda)
+        return _ops.td_lambda_op(next_state_value, reward, done, done if terminated is None else terminated, g, l, gt, lt,
+                                 -1 if rolling_gamma is None else int(bool(rolling_gamma)), time_dim, True)
     if terminated is None:
         terminated = done
     if not (next_state_value.shape == reward.shape == done.shape == terminated.shape):
@@ -1260,6 +1387,10 @@ def vtrace_advantage_estimate(
 
     Returns ``(advantages, vs)``.  ``terminated=None`` makes ``not_terminated = not_done``.
     """
+    if torch.compiler.is_compiling():
+        (g, gt), (rs, rt), (cs, ct) = _ops._split(gamma), _ops._split(rho_thresh), _ops._split(c_thresh)
+        return _ops.vtrace_op(log_pi, log_mu, state_value, next_state_value, reward, done, done if terminated is None else terminated,
+                              g, gt, rs, cs, rt, ct, time_dim)
     call = _prepare_vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward, done, terminated,
                            rho_thresh, c_thresh, time_dim)
     if _needs_grad(log_pi, log_mu, state_value, next_state_value, reward, gamma):
@@ -1380,6 +1511,10 @@ def td1_return_estimate(
     ``g = r + gamma*nt*((1-dnt)*g + dnt*v')`` with ``dnt = done & ~terminated``, starting from the raw
     ``v'_{T-1}``; ``rolling_gamma=False`` (needs a gamma tensor of the inputs' shape) reruns every tail with
     its first step's gamma from ``g = 0``, as the reference's loop does (``trl_td1_fwd``)."""
+    if torch.compiler.is_compiling():
+        g, gt = _ops._split(gamma)
+        return _ops.td1_op(next_state_value, reward, done, done if terminated is None else terminated, g, gt,
+                           -1 if rolling_gamma is None else int(bool(rolling_gamma)), time_dim)
     call = _prepare_td1(gamma, next_state_value, reward, done, terminated, rolling_gamma, time_dim)
     if _needs_grad(next_state_value, reward, gamma):
         return _Td1Function.apply(next_state_value, reward, _coef_leaf(gamma, call.shape, time_dim), call,
@@ -1429,6 +1564,8 @@ def reward2go(reward, done, gamma, *, time_dim: int = -2):
     ``R_t = r_t + gamma * (1-done_t) * R_{t+1}`` restarting after every ``done`` and at the end
     of every row: GAE with ``v = v' = 0`` and ``lmbda*gamma -> gamma``.  Like the reference, a
     tensor with more than two dims is flattened so that trailing dims are independent rows."""
+    if torch.compiler.is_compiling() and not isinstance(gamma, torch.Tensor):
+        return _ops.reward2go_op(reward, done, float(gamma), time_dim)
     if reward.shape != done.shape:
         raise ValueError(f"reward and done must share the same shape, got {reward.shape} and {done.shape}")
     zeros = torch.zeros_like(reward)
@@ -1440,17 +1577,14 @@ def reward2go(reward, done, gamma, *, time_dim: int = -2):
 
 
 # ---------------------------------------------------------------------------------------------
-# torch.compile: every entry point is one native launch behind ctypes -- there is nothing for a
-# tracing compiler to fuse, and dynamo cannot look through ctypes.  The entry points are marked
-# opaque, so a compiled region that calls them runs them eagerly between its own graphs (the
-# reference instead flips its estimators to the Python loop under dynamo, advantages.py:1303-1307).
+# torch.compile: dynamo cannot look through ctypes, so while compiling every estimator above dispatches to a
+# torch.library custom op with a fake implementation (_ops.py): torch.compile(fullgraph=True) traces a PPO-style
+# function without graph breaks (the reference instead flips its estimators to the Python loop under dynamo,
+# advantages.py:1303-1307).  Eager calls never pay the dispatcher: they go straight to the library.  The helpers
+# below have no op of their own and stay opaque (a graph break).
 # ---------------------------------------------------------------------------------------------
-_OPAQUE = (
-    "generalized_advantage_estimate", "vec_generalized_advantage_estimate", "gae_with_stats", "gae_normalized",
-    "td_lambda_return_estimate", "vec_td_lambda_return_estimate", "td_lambda_advantage_estimate",
-    "vec_td_lambda_advantage_estimate", "vtrace_advantage_estimate", "td1_return_estimate", "vec_td1_return_estimate",
-    "td1_advantage_estimate", "vec_td1_advantage_estimate", "reward2go", "moments", "normalize_", "standardize",
-)
-for _name in _OPAQUE:
+from . import _ops  # noqa: E402  (imports this module back; used only inside the functions above)
+
+for _name in ("gae_with_stats", "moments", "normalize_"):
     globals()[_name] = torch.compiler.disable(globals()[_name], recursive=True)
 del _name
