@@ -217,3 +217,36 @@ def test_steps_to_next_obs_scales_gamma():
     eadv, _ = O.gae(gam, torch.tensor(0.94), c("state_value"), c(("next", "state_value")), c(("next", "reward")),
                     c(("next", "done")), c(("next", "terminated")))
     torch.testing.assert_close(d.get("advantage").cpu(), eadv, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_differentiable_normalisation_keeps_the_graph():
+    """VTrace(average_adv=True, differentiable=True) and TDLambdaEstimator(average_rewards=True, differentiable=True):
+    the normalisation is the reference's differentiable torch ops (advantages.py:1828-1832, 1160-1165), so the gradient
+    reaches the reward; with differentiable=False the outputs are leaves."""
+    for diff in (True, False):
+        d = _data(seed=7)
+        reward = d.get(("next", "reward")).clone().requires_grad_(True)
+        d.set(("next", "reward"), reward)
+        g = torch.Generator().manual_seed(9)
+        log_pi = torch.rand(4, 10, 1, generator=g).log().to(DEV)
+        VTrace(gamma=0.98, actor_network=lambda data: log_pi, value_network=None, average_adv=True, differentiable=diff)(d)
+        adv = d.get("advantage")
+        assert adv.requires_grad == diff
+        if diff:
+            adv.pow(2).sum().backward()
+            assert reward.grad is not None and reward.grad.norm() > 0
+        else:
+            assert adv.is_leaf
+
+
+@pytest.mark.gpu
+def test_host_mirror_keeps_one_entry_per_buffer():
+    """looking gamma then lmbda up must not evict each other (a device buffer would be synchronised on
+    every forward): the second look-up of a buffer returns the SAME host copy."""
+    m = GAE(gamma=0.98, lmbda=0.94, value_network=None).to(DEV)
+    g1, l1 = m._host(m.gamma), m._host(m.lmbda)
+    assert g1.device.type == "cpu" and l1.device.type == "cpu"
+    assert m._host(m.gamma) is g1 and m._host(m.lmbda) is l1 and m._host(m.gamma) is g1
+    m.gamma.fill_(0.5)  # in-place update: the mirror is refreshed
+    assert float(m._host(m.gamma)) == 0.5

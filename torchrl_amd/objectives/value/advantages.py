@@ -269,29 +269,37 @@ class ValueEstimatorBase(nn.Module, metaclass=abc.ABCMeta):
     def out_keys(self):
         return [self.tensor_keys.advantage, self.tensor_keys.value_target]
 
+    @staticmethod
+    def _normalise_key(value):
+        """A key name in canonical form: str / tuple (nested) / list of those; anything else is rejected with the
+        reference's messages (advantages.py:306-315)."""
+        if isinstance(value, list):
+            return [_unravel_key(k) for k in value]
+        if isinstance(value, (str, tuple)):
+            return _unravel_key(value)
+        if value is None:
+            raise ValueError("tensordict keys cannot be None")
+        raise ValueError(f"key name must be of type NestedKey (Union[str, Tuple[str]]) but got {type(value)}")
+
     def set_keys(self, **kwargs) -> None:
-        """Set tensordict key names."""
-        for key, value in list(kwargs.items()):
-            if isinstance(value, list):
-                value = [_unravel_key(k) for k in value]
-            elif not isinstance(value, (str, tuple)):
-                if value is None:
-                    raise ValueError("tensordict keys cannot be None")
-                raise ValueError(f"key name must be of type NestedKey (Union[str, Tuple[str]]) but got {type(value)}")
-            else:
-                value = _unravel_key(value)
-            if key not in self._AcceptedKeys.__dict__:
-                raise KeyError(f"{key} is not an accepted tensordict key for advantages")
-            if key == "value" and hasattr(self.value_network, "out_keys") and (value not in self.value_network.out_keys):
-                raise KeyError(f"value key '{value}' not found in value network out_keys {self.value_network.out_keys}")
-            kwargs[key] = value
-        if self._tensor_keys is None:
-            conf = asdict(self.default_keys())
-            conf.update(self.dep_keys)
+        """Rename tensordict entries the estimator reads / writes (behaviour of the reference's ``set_keys``,
+        advantages.py:303-336: unknown names raise ``KeyError``, a ``value`` key must be one of the value network's
+        ``out_keys``; the new names are merged over the current configuration)."""
+        accepted = self._AcceptedKeys.__dict__
+        net_out = getattr(self.value_network, "out_keys", None)
+        renamed = {}
+        for name, raw in kwargs.items():
+            key = self._normalise_key(raw)
+            if name not in accepted:
+                raise KeyError(f"{name} is not an accepted tensordict key for advantages")
+            if name == "value" and net_out is not None and key not in net_out:
+                raise KeyError(f"value key '{key}' not found in value network out_keys {net_out}")
+            renamed[name] = key
+        if self._tensor_keys is not None:
+            current = asdict(self._tensor_keys)
         else:
-            conf = asdict(self._tensor_keys)
-        conf.update(kwargs)
-        self._tensor_keys = self._AcceptedKeys(**conf)
+            current = {**asdict(self.default_keys()), **self.dep_keys}
+        self._tensor_keys = self._AcceptedKeys(**{**current, **renamed})
 
     is_functional = property(lambda self: False)
     is_stateless = property(lambda self: False)
@@ -308,7 +316,10 @@ class ValueEstimatorBase(nn.Module, metaclass=abc.ABCMeta):
             import weakref
 
             hit = (t._version, weakref.ref(t), t.detach().cpu())
-            self._host_cache = {key: hit}  # one live generation is enough
+            # one entry per buffer (gamma, lmbda, thresholds are looked up in turn); entries of dead tensors are dropped
+            for k in [k for k, h in self._host_cache.items() if h[1]() is None]:
+                del self._host_cache[k]
+            self._host_cache[key] = hit
         return hit[2]
 
     def _get_time_dim(self, time_dim: Optional[int], data) -> int:

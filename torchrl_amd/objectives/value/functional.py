@@ -1027,6 +1027,10 @@ def standardize(x: torch.Tensor, eps: float, group=None, distributed: bool = Fal
     all-reduce -- so every rank normalises with the global statistics of the sharded batch."""
     if torch.compiler.is_compiling() and not distributed and group is None:
         return _ops.standardize_op(x, float(eps))
+    if torch.is_grad_enabled() and x.requires_grad and not distributed and group is None:
+        # differentiable input (differentiable=True estimators): the reference's own torch ops keep the graph
+        # (advantages.py:1160-1165, 1828-1832); the single-launch kernel serves the no-grad case
+        return (x - x.mean()) / x.std().clamp_min(eps)
     xc = x.detach().contiguous()
     if (distributed or group is not None) and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
         st = moments(xc)
