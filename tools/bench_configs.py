@@ -93,6 +93,34 @@ def main():
         report(f"C5 [1024x10000] V-trace {nm} tensor gamma", timeit(lambda: F.vtrace_advantage_estimate(gam, lp, lm, v, nv, r, d, t), it), n, 6 * b + 2 + 2 * b)
         report(f"C5 [1024x10000] GAE {nm} tensor gamma", timeit(lambda: F.generalized_advantage_estimate(gam, 0.95, v, nv, r, d, t), it), n, 4 * b + 2 + 2 * b)
         report(f"C5 [1024x10000] GAE {nm} scalar gamma", timeit(lambda: F.generalized_advantage_estimate(0.99, 0.95, v, nv, r, d, t), it), n, 3 * b + 2 + 2 * b)
+    # backward kernels: device time of the backward launch alone, C4 and C5 shapes
+    import ctypes  # noqa: F401
+    from torchrl_amd import _extension
+    lib = _extension.get_lib()
+    for name, shape, dt, b in (("C4 [65536x32]", (65536, 32, 1), f32, 4), ("C5 [1024x10000]", (1024, 10000, 1), f32, 4),
+                               ("C5 [1024x10000]", (1024, 10000, 1), f64, 8)):
+        nm = "f32" if dt == f32 else "f64"
+        r, v, nv, d, t, gam, lp, lm = inputs(shape, dt, 0.01)
+        n = r.numel()
+        c = F._prepare_gae(0.99, 0.95, v, nv, r, d, t, -2)
+        ga, gv = torch.randn_like(r), torch.randn_like(r)
+        F._gae_bwd(c, ga, gv, True, True, True)
+        us = timeit(lambda: F._gae_bwd(c, ga, gv, True, True, True), it)
+        print(f"{name + ' GAE backward ' + nm:58s} {us:9.2f} us  {n / us * 1e6:10.3e} trans/s  {n * (5 * b + 2) / 1e6:8.1f} MB  "
+              f"{n * (5 * b + 2) / us * 1e-3:8.1f} GB/s  {n * (5 * b + 2) / us * 1e-3 / 8000:6.1%}  [{F.last_bwd_kernel()}]")
+        ct = F._prepare_td_lambda(gam, 0.95, nv, r, d, t, None, -2)
+        F._td_bwd(ct, ga, False, True, True)
+        us = timeit(lambda: F._td_bwd(ct, ga, False, True, True), it)
+        bt = 4 * b + 2  # g_ret + gamma read, 2 written
+        print(f"{name + ' TD(lambda) backward ' + nm + ' tensor gamma':58s} {us:9.2f} us  {n / us * 1e6:10.3e} trans/s  {n * bt / 1e6:8.1f} MB  "
+              f"{n * bt / us * 1e-3:8.1f} GB/s  {n * bt / us * 1e-3 / 8000:6.1%}  [{F.last_bwd_kernel()}]")
+        cv = F._prepare_vtrace(0.99, lp, lm, v, nv, r, d, t, 1.0, 1.0, -2)
+        _, vs = F._launch_vtrace(cv)
+        F._vtrace_bwd(cv, ga, gv, vs, (True,) * 5, False)
+        us = timeit(lambda: F._vtrace_bwd(cv, ga, gv, vs, (True,) * 5, False), it)
+        bv = 13 * b + 2  # 8 tensors read, 5 written
+        print(f"{name + ' V-trace backward ' + nm:58s} {us:9.2f} us  {n / us * 1e6:10.3e} trans/s  {n * bv / 1e6:8.1f} MB  "
+              f"{n * bv / us * 1e-3:8.1f} GB/s  {n * bv / us * 1e-3 / 8000:6.1%}  [{F.last_bwd_kernel()}]")
 
 
 if __name__ == "__main__":

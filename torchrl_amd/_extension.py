@@ -17,7 +17,8 @@ import os
 import warnings
 
 _LIB_NAME = "libtrl_value.so"
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
+# TRL_VALUE_LIB: development switch (kernel variants built beside the product library); unset in normal use
+_LIB_PATH = os.environ.get("TRL_VALUE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
 ABI_VERSION = 5
 
 EXTENSION_WARNING = (

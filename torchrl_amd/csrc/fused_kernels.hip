@@ -68,24 +68,6 @@ __device__ __forceinline__ unsigned long long tag_bits(double x, unsigned tag) {
 }
 __device__ __forceinline__ double untag(unsigned long long b) { return __longlong_as_double((long long)(b & ~0xffull)); }
 
-// 16-byte write-through store (global_store_dwordx4 sc1); other widths (ragged tails) as plain element stores.
-// The s_nop: a store of more than 64 bits reads its data registers one wait state after issue, and the compiler
-// does not know this asm is such a store (it may overwrite the registers with the very next instruction).
-template <bool VEC, typename T, int V>
-__device__ __forceinline__ void store_wt(T *__restrict__ p, i64 flat, int nvalid, const T (&in)[V]) {
-    if constexpr (VEC && V * sizeof(T) == 16) {
-        if (nvalid == V) {
-            u32x4 raw;
-            __builtin_memcpy(&raw, in, 16);
-            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p + flat), "v"(raw) : "memory");
-            return;
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < V; ++e)
-        if (e < nvalid) p[flat + e] = in[e];
-}
-
 // FULL: every team's K chunks are complete (nchunks == K * grid * kTeams, whole chunks of 256*V elements, aligned):
 //       no clipping, every lane holds V valid elements -- the C4 shape class; 0.6 us per launch at [65536 x 32].
 // XCHG: the batch is sharded over GPUs; the moments are summed over the ranks inside the launch (xchg.h).

@@ -148,6 +148,24 @@ __device__ __forceinline__ void store_n_rev(T *__restrict__ p, i64 n_total, i64 
         if (e < nvalid) p[n_total - 1 - flat - e] = in[e];
 }
 
+// 16-byte write-through store (global_store_dwordx4 sc1); other widths (ragged tails) as plain element stores.
+// The s_nop: a store of more than 64 bits reads its data registers one wait state after issue, and the compiler
+// does not know this asm is such a store (it may overwrite the registers with the very next instruction).
+template <bool VEC, typename T, int V>
+__device__ __forceinline__ void store_wt(T *__restrict__ p, i64 flat, int nvalid, const T (&in)[V]) {
+    if constexpr (VEC && V * sizeof(T) == 16) {
+        if (nvalid == V) {
+            u32x4 raw;
+            __builtin_memcpy(&raw, in, 16);
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p + flat), "v"(raw) : "memory");
+            return;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+        if (e < nvalid) p[flat + e] = in[e];
+}
+
 template <typename T>
 __device__ __forceinline__ T clamp_max_nan(T x, T hi) { return (x != x) ? x : (x > hi ? hi : x); }
 __device__ __forceinline__ float exp_t(float x) { return expf(x); }

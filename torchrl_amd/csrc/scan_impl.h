@@ -642,6 +642,7 @@ template <template <typename, typename, int> class OpT, typename Args, typename 
 LaunchResult dispatch_scan(int vdt, int cdt, F &&f) {
     // V = 16 bytes of the storage dtype per lane
     if (vdt == 0 && cdt == 0) return f(OpT<float, float, 4>{});
+    // (fp64 with V = 4, two 16-byte loads per tensor and lane, was measured at C5: 0 - 5 % slower than V = 2 on every kernel)
     if (vdt == 1 && cdt == 1) return f(OpT<double, double, 2>{});
     if (vdt == 1 && cdt == 0) return f(OpT<double, float, 2>{});
     if (vdt == 0 && cdt == 1) return f(OpT<float, double, 4>{});

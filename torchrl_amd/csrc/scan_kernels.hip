@@ -1,5 +1,6 @@
 // SCAN family, forward estimators: instantiations of scan_impl.h behind the launch_*_scan entry points.
 #include "scan_impl.h"
+#include "gae_interleaved.h"
 
 
 size_t scan_lookback_bytes(i64 O, i64 T, i64 I) {
@@ -24,6 +25,10 @@ LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a, 
         typedef decltype(op) Op;
         Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus(), lb_ws ? lb_bytes : 0, a.partials != nullptr);
         if (!p.ok) return LaunchResult{2, 0, nullptr};
+        if constexpr (!Op::kShifted) {
+            // I > 1: the GAE-specific kernel (delta / disc formed before the LDS turn, gae_interleaved.h)
+            if (p.interleaved) return launch_gae_interleaved<typename Op::TS, typename Op::TG, Op::V>(s, a, p, device_cus());
+        }
         return launch_scan<Op>(s, a, p, a.O, a.T, a.I, a.partials,
                                p.interleaved ? "gae_scan_interleaved" : p.lookback ? "gae_scan_lookback" : p.long_rows ? "gae_scan_long" : "gae_scan_short", lb_ws);
     };
