@@ -55,6 +55,7 @@ def test_c3_vmas_4096x100x5_expanded_masks():
     term_d = term.to(DEV).expand(shape)            # stride-0 views, as DoneTransform produces
     done_d = (term | trunc).to(DEV).expand(shape)
     adv, vt = F.generalized_advantage_estimate(cs["gamma"], cs["lmbda"], v.to(DEV), nv.to(DEV), r.to(DEV), done_d, term_d, time_dim=-3)
+    assert "interleaved" in F.last_kernel()
     _check_summary(adv, cs["advantage"], 1e-5, 1e-5)
     _check_summary(vt, cs["value_target"], 1e-5, 1e-5)
 

@@ -121,3 +121,33 @@ def test_vtrace_threshold_tensors_golden(meta):
     assert F.last_kernel() == "vtrace_seq"
     check(adv, a["advantage"], False)
     check(vs, a["vs"], False)
+
+
+@pytest.mark.parametrize("shape,time_dim", [((7, 33, 3, 2), -3), ((5, 4, 9), -1), ((3, 50, 4), 1), ((2, 3, 40, 5, 1), 2),
+                                            ((4096, 100, 5, 1), -3)])
+@pytest.mark.parametrize("masks", ["full", "expanded"])
+@pytest.mark.parametrize("eps", [None, 1e-4])
+def test_gae_fast_path_any_time_dim(shape, time_dim, masks, eps):
+    """The python fast path (float gamma / lmbda, dense tensors) with time anywhere and per-step masks expanded over the feature
+    dims, against the CPU oracle and against the general path (0-dim tensor gamma routes around the fast path)."""
+    g = torch.Generator().manual_seed(3)
+    r, v, nv = (torch.randn(shape, generator=g) for _ in range(3))
+    td = time_dim % len(shape)
+    mshape = shape if masks == "full" else shape[:td + 1] + (1,) * (len(shape) - td - 1)
+    term_c = torch.rand(mshape, generator=g) < 0.05
+    done_c = term_c | (torch.rand(mshape, generator=g) < 0.05)
+    ra, rvt = O.gae(0.99, 0.95, v, nv, r, done_c.expand(shape).contiguous(), term_c.expand(shape).contiguous(), time_dim=time_dim)
+    dv, dnv, dr = cu(v), cu(nv), cu(r)
+    dd, dt_ = cu(done_c).expand(shape), cu(term_c).expand(shape)   # stride-0 views over the feature dims when "expanded"
+    if eps is None:
+        adv, vt = F.generalized_advantage_estimate(0.99, 0.95, dv, dnv, dr, dd, dt_, time_dim=time_dim)
+        gadv, gvt = F.generalized_advantage_estimate(torch.tensor(0.99), 0.95, dv, dnv, dr, dd, dt_, time_dim=time_dim)
+        torch.testing.assert_close(adv.cpu(), ra, **tol(ra.dtype))
+        torch.testing.assert_close(vt.cpu(), rvt, **tol(ra.dtype))
+        torch.testing.assert_close(adv, gadv, **tol(ra.dtype))
+        torch.testing.assert_close(vt, gvt, **tol(ra.dtype))
+    else:
+        adv, vt = F.gae_normalized(0.99, 0.95, dv, dnv, dr, dd, dt_, eps=eps, time_dim=time_dim)
+        ref = O.normalize(ra, eps)
+        torch.testing.assert_close(adv.cpu(), ref, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(vt.cpu(), rvt, **tol(ra.dtype))

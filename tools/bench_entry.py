@@ -24,18 +24,21 @@ def per_call(fn, n=2000):
     return (time.perf_counter() - t0) / n * 1e6
 
 
-for name, shape in (("C1 [1x2048]", (1, 2048, 1)), ("C2 [8x128]", (8, 128, 1)), ("C4 [65536x32]", (65536, 32, 1))):
+for name, shape, td in (("C1 [1x2048]", (1, 2048, 1), -2), ("C2 [8x128]", (8, 128, 1), -2), ("C3 [4096x100x5]", (4096, 100, 5, 1), -3),
+                        ("C4 [65536x32]", (65536, 32, 1), -2)):
     g = torch.Generator().manual_seed(0)
     r, v, nv = (torch.randn(shape, generator=g).to(DEV) for _ in range(3))
-    term = (torch.rand(shape, generator=g) < 0.01).to(DEV)
-    done = term | (torch.rand(shape, generator=g) < 0.01).to(DEV)
-    call = F._prepare_gae(0.99, 0.95, v, nv, r, done, term, -2)
+    mshape = shape[:len(shape) + td + 1] + (1,) * (-td - 1)
+    term = (torch.rand(mshape, generator=g) < 0.01).to(DEV)
+    done = (term | (torch.rand(mshape, generator=g) < 0.01).to(DEV)).expand(shape)   # per-step masks, expanded over the agents
+    term = term.expand(shape)
+    call = F._prepare_gae(0.99, 0.95, v, nv, r, done, term, td)
     k_gae = per_call(F.prepare_gae_step(call, normalize=False).run)
     k_norm = per_call(F.prepare_gae_step(call, 1e-4, normalize=True).run)
-    e_gae = per_call(lambda: F.generalized_advantage_estimate(0.99, 0.95, v, nv, r, done, term))
-    e_vec = per_call(lambda: F.vec_generalized_advantage_estimate(0.99, 0.95, v, nv, r, done, term))
-    e_norm = per_call(lambda: F.gae_normalized(0.99, 0.95, v, nv, r, done, term, eps=1e-4))
-    e_gen = per_call(lambda: F.generalized_advantage_estimate(torch.tensor(0.99), 0.95, v, nv, r, done, term))
-    print(f"{name:14s} bound call: gae {k_gae:6.2f} us, gae+normalise {k_norm:6.2f} us | public API: generalized_advantage_estimate "
+    e_gae = per_call(lambda: F.generalized_advantage_estimate(0.99, 0.95, v, nv, r, done, term, time_dim=td))
+    e_vec = per_call(lambda: F.vec_generalized_advantage_estimate(0.99, 0.95, v, nv, r, done, term, time_dim=td))
+    e_norm = per_call(lambda: F.gae_normalized(0.99, 0.95, v, nv, r, done, term, eps=1e-4, time_dim=td))
+    e_gen = per_call(lambda: F.generalized_advantage_estimate(torch.tensor(0.99), 0.95, v, nv, r, done, term, time_dim=td))
+    print(f"{name:16s} bound call: gae {k_gae:6.2f} us, gae+normalise {k_norm:6.2f} us | public API: generalized_advantage_estimate "
           f"{e_gae:6.2f} ({e_gae / k_gae:4.2f}x), vec {e_vec:6.2f}, gae_normalized {e_norm:6.2f} ({e_norm / k_norm:4.2f}x), "
           f"general path (0-dim gamma tensor) {e_gen:6.2f}", flush=True)

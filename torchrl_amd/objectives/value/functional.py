@@ -725,7 +725,22 @@ _FAST_NEED = {}   # (O, T, I) -> trl_workspace_bytes
 _T32, _T64, _TBOOL = torch.float32, torch.float64, torch.bool
 
 
-def _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, terminated, eps, algo=ALGO_AUTO):
+def _step_mask(m: torch.Tensor, shape, td: int) -> bool:
+    """True when ``m`` is a per-step mask expanded (stride 0) over the dims after time: its ``[O, T]`` bytes are dense."""
+    st = m.stride()
+    acc = 1
+    for k in range(len(shape) - 1, -1, -1):
+        if k > td:
+            if st[k] != 0 and shape[k] != 1:
+                return False
+        else:
+            if st[k] != acc and shape[k] != 1:
+                return False
+            acc *= shape[k]
+    return True
+
+
+def _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, terminated, eps, algo=ALGO_AUTO, time_dim=-2):
     """``(advantage, value_target)`` through the fast path (``eps`` not None: normalised advantage), or None."""
     if type(gamma) is not float or type(lmbda) is not float:
         return None
@@ -743,9 +758,17 @@ def _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, termina
     if dev.type != "cuda" or dev.index != torch.cuda.current_device() or state_value.device != dev or reward.device != dev \
             or done.device != dev or terminated.device != dev:
         return None
-    if not (nsv.is_contiguous() and state_value.is_contiguous() and reward.is_contiguous() and done.is_contiguous()
-            and terminated.is_contiguous()):
+    if not (nsv.is_contiguous() and state_value.is_contiguous() and reward.is_contiguous()):
         return None
+    nd = len(shape)
+    td = time_dim + nd if time_dim < 0 else time_dim
+    if not 0 <= td < nd - 1:
+        return None
+    bcast = 0
+    if not (done.is_contiguous() and terminated.is_contiguous()):
+        if not (_step_mask(done, shape, td) and _step_mask(terminated, shape, td)):
+            return None
+        bcast = 1   # one byte per (outer row, step), shared by the feature elements (VMAS: done expanded over the agents)
     if torch.is_grad_enabled() and (nsv.requires_grad or state_value.requires_grad or reward.requires_grad):
         return None
     n = nsv.numel()
@@ -760,7 +783,10 @@ def _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, termina
         if cdt not in _DT:
             return None
         coef = _FAST_COEF[key] = (g_val, lg_val, _DT[cdt])
-    T, I = shape[-2], shape[-1]
+    T = shape[td]
+    I = 1
+    for k in range(td + 1, nd):
+        I *= shape[k]
     O = n // (T * I)
     lib = _extension.get_lib()
     stream = torch._C._cuda_getCurrentRawStream(dev.index)
@@ -768,7 +794,7 @@ def _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, termina
     if eps is None:
         ws = _lookback_workspace(lib, dev, O, T, I) if (I == 1 and T >= 2048 and O < 4096) else None
         rc = lib.trl_gae_fwd(stream, _DT[dt], coef[2], reward.data_ptr(), state_value.data_ptr(), nsv.data_ptr(),
-                             done.data_ptr(), terminated.data_ptr(), 0, None, None, coef[0], 0.0, coef[1], O, T, I,
+                             done.data_ptr(), terminated.data_ptr(), bcast, None, None, coef[0], 0.0, coef[1], O, T, I,
                              adv.data_ptr(), vt.data_ptr(), None, None if ws is None else ws.data_ptr(),
                              0 if ws is None else ws.numel(), algo)
     else:
@@ -780,7 +806,7 @@ def _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, termina
         if ws is None or ws.numel() < need:
             ws = _workspace(lib, dev, O, T, I)
         rc = lib.trl_gae_normalize_fwd(stream, _DT[dt], coef[2], reward.data_ptr(), state_value.data_ptr(), nsv.data_ptr(),
-                                       done.data_ptr(), terminated.data_ptr(), 0, None, None, coef[0], 0.0, coef[1], O, T, I,
+                                       done.data_ptr(), terminated.data_ptr(), bcast, None, None, coef[0], 0.0, coef[1], O, T, I,
                                        adv.data_ptr(), vt.data_ptr(), eps, None, ws.data_ptr(), ws.numel(), algo)
     if rc:
         _extension.check(rc, lib)
@@ -822,10 +848,9 @@ def generalized_advantage_estimate(
         (g, gt), (l, lt) = _ops._split(gamma), _ops._split(lmbda)
         return _ops.gae_op(state_value, next_state_value, reward, done, done if terminated is None else terminated, g, l, gt, lt,
                            time_dim, False)
-    if time_dim == -2:
-        out = _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, terminated, None)
-        if out is not None:
-            return out
+    out = _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, terminated, None, ALGO_AUTO, time_dim)
+    if out is not None:
+        return out
     call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
     if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
         return _GaeFunction.apply(state_value, next_state_value, reward, _coef_leaf(gamma, call.shape, time_dim),
@@ -851,10 +876,9 @@ def vec_generalized_advantage_estimate(
         (g, gt), (l, lt) = _ops._split(gamma), _ops._split(lmbda)
         return _ops.gae_op(state_value, next_state_value, reward, done, done if terminated is None else terminated, g, l, gt, lt,
                            time_dim, True)
-    if time_dim == -2:
-        out = _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, terminated, None)
-        if out is not None:
-            return out
+    out = _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, terminated, None, ALGO_AUTO, time_dim)
+    if out is not None:
+        return out
     call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
     call.out_dtype = state_value.dtype  # functional.py:314
     if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
@@ -944,8 +968,8 @@ def gae_normalized(gamma, lmbda, state_value, next_state_value, reward, done, te
         (g, gt), (l, lt) = _ops._split(gamma), _ops._split(lmbda)
         return _ops.gae_normalized_op(state_value, next_state_value, reward, done, done if terminated is None else terminated, g, l,
                                       gt, lt, float(eps), time_dim)
-    if time_dim == -2 and exchange is None and group is None and not distributed:
-        out = _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, terminated, float(eps), algo)
+    if exchange is None and group is None and not distributed:
+        out = _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, terminated, float(eps), algo, time_dim)
         if out is not None:
             return out
     call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
