@@ -358,6 +358,7 @@ def main():
         }
         if entry_point_ms is not None:
             out["entry_point_ms"] = entry_point_ms
+            out["entry_point_host"] = "cxx" if F.host_fast_path() else "python"
         if routes:
             out["config"]["route_ms_per_step"] = routes
         if os.environ.get("TRL_BENCH_REHEARSAL"):

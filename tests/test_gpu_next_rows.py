@@ -127,9 +127,15 @@ def test_vtrace_threshold_tensors_golden(meta):
                                             ((4096, 100, 5, 1), -3)])
 @pytest.mark.parametrize("masks", ["full", "expanded"])
 @pytest.mark.parametrize("eps", [None, 1e-4])
-def test_gae_fast_path_any_time_dim(shape, time_dim, masks, eps):
-    """The python fast path (float gamma / lmbda, dense tensors) with time anywhere and per-step masks expanded over the feature
+@pytest.mark.parametrize("host", ["cxx", "python"])
+def test_gae_fast_path_any_time_dim(shape, time_dim, masks, eps, host, monkeypatch):
+    """Both hosts of the fast path (csrc/host_fast.cpp's module, and the python route a tree without it takes): the fast path (float gamma / lmbda, dense tensors) with time anywhere and per-step masks expanded over the feature
     dims, against the CPU oracle and against the general path (0-dim tensor gamma routes around the fast path)."""
+    if host == "cxx":
+        assert F.host_fast_path(), "lib/_trl_host.so is not built (make -C torchrl_amd/csrc)"
+    else:
+        F.host_fast_path()
+        monkeypatch.setattr(F, "_HOST", None)
     g = torch.Generator().manual_seed(3)
     r, v, nv = (torch.randn(shape, generator=g) for _ in range(3))
     td = time_dim % len(shape)

@@ -195,3 +195,21 @@ def test_shifted_pair_detection():
     tm = torch.randn(11, 6, 1)                                    # time-major storage seen batch-first
     assert not sp(tm[:-1].transpose(0, 1), tm[1:].transpose(0, 1))
     assert not sp(torch.empty(0, 11, 1)[:, :-1], torch.empty(0, 11, 1)[:, 1:])
+
+
+def test_host_module_declines_what_the_fast_path_does_not_cover():
+    """csrc/host_fast.cpp: loads beside the library, returns None (-> python's general path, which raises the reference's
+    errors) for CPU tensors, tensor coefficients, mismatched shapes; no compute call is made without a GPU."""
+    from torchrl_amd import _extension
+    from torchrl_amd.objectives.value import functional as F
+    if _extension.get_host() is None:
+        pytest.skip("lib/_trl_host.so not built")
+    assert F.host_fast_path()
+    x = torch.zeros(2, 5, 1)
+    m = torch.zeros(2, 5, 1, dtype=torch.bool)
+    assert F._HOST.gae(0.99, 0.95, x, x, x, m, m, None, 0, -2) is None            # not on a HIP device
+    assert F._HOST.gae(torch.tensor(0.99), 0.95, x, x, x, m, m, None, 0, -2) is None
+    assert F._HOST.gae(0.99, 0.95, x, x[:1], x, m, m, None, 0, -2) is None
+    assert F._HOST.gae(0.99, 0.95, x, x, x, m.float(), m, None, 0, -2) is None
+    with pytest.raises(TypeError):
+        F._HOST.gae(0.99, 0.95, x)

@@ -124,6 +124,36 @@ def _init_extension():
         warnings.warn(EXTENSION_WARNING + (f" [{_load_error}]" if _load_error else ""))
 
 
+_host = False  # False: not tried yet; None: absent / disabled; else the _trl_host module
+
+
+def get_host():
+    """The host-side fast-path module (csrc/host_fast.cpp, built beside the library as lib/_trl_host.so) or None when it is
+    not built or ``TRL_NO_HOST_SHIM=1``: the python entry points then make the same C-ABI call from python (same kernels, a
+    few microseconds more host time per call)."""
+    global _host
+    if _host is False:
+        _host = None
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "_trl_host.so")
+        if os.environ.get("TRL_NO_HOST_SHIM") != "1" and os.path.exists(path):
+            import importlib.machinery
+            import importlib.util
+            try:
+                loader = importlib.machinery.ExtensionFileLoader("_trl_host", path)
+                spec = importlib.util.spec_from_file_location("_trl_host", path, loader=loader)
+                mod = importlib.util.module_from_spec(spec)
+                loader.exec_module(mod)
+                _host = mod
+            except ImportError as e:  # built against another torch: say so once, keep the python route
+                warnings.warn(f"torchrl_amd: host fast-path module {path} failed to load ({e}); using the python route")
+    return _host
+
+
+def fn_address(fn) -> int:
+    """Address of a ctypes function of the loaded library (handed to the host module)."""
+    return ctypes.cast(fn, ctypes.c_void_p).value
+
+
 def get_lib():
     """Return the loaded library or raise loudly -- there is no fallback path."""
     lib = _load()

@@ -339,6 +339,8 @@ def _workspace(lib, dev, O, T, I):
     if ws is None or ws.numel() < need:
         ws = torch.zeros(max(need, 1 << 16), dtype=torch.uint8, device=dev)
         _WORKSPACES[key] = ws
+        if _HOST:   # the host module mirrors this table: it must never keep the address of a replaced workspace
+            _HOST.set_workspace(key[0], key[1], ws.data_ptr(), ws.numel())
     return ws
 
 
@@ -725,6 +727,49 @@ _FAST_NEED = {}   # (O, T, I) -> trl_workspace_bytes
 _T32, _T64, _TBOOL = torch.float32, torch.float64, torch.bool
 
 
+_HOST = None   # the _trl_host module once _host_module() has initialised it
+
+
+def _fast_coef(gamma: float, lmbda: float):
+    """``(gamma, lmbda*gamma)`` as the reference's products with an int32 mask round them, and the coefficient dtype code."""
+    g_val, g_dt = _scalar_mask_coef(gamma)
+    lg_val, lg_dt = _scalar_mask_coef(lmbda * gamma)
+    cdt = torch.promote_types(g_dt, lg_dt)
+    if cdt not in _DT:
+        return None
+    return g_val, lg_val, _DT[cdt]
+
+
+def _host_workspace(dev_index: int, O: int, T: int, I: int):
+    dev = torch.device("cuda", dev_index)
+    ws = _workspace(_extension.get_lib(), dev, O, T, I)
+    _HOST.set_workspace(dev_index, _stream(dev), ws.data_ptr(), ws.numel())
+
+
+def _host_module():
+    """Load and initialise csrc/host_fast.cpp's module (once); None when it is not there."""
+    global _HOST, _HOST_TRIED
+    if not _HOST_TRIED:
+        _HOST_TRIED = True
+        mod = _extension.get_host()
+        if mod is not None:
+            lib = _extension.get_lib()
+            mod.init(_extension.fn_address(lib.trl_gae_fwd), _extension.fn_address(lib.trl_gae_normalize_fwd),
+                     _extension.fn_address(lib.trl_workspace_bytes), _fast_coef, _host_workspace, torch._C._cuda_getCurrentRawStream)
+            for (di, st), ws in _WORKSPACES.items():
+                mod.set_workspace(di, st, ws.data_ptr(), ws.numel())
+            _HOST = mod
+    return _HOST
+
+
+_HOST_TRIED = False
+
+
+def host_fast_path() -> bool:
+    """True when the GAE entry points go through the C++ host module (bench.py reports it beside entry_point_ms)."""
+    return _host_module() is not None
+
+
 def _step_mask(m: torch.Tensor, shape, td: int) -> bool:
     """True when ``m`` is a per-step mask expanded (stride 0) over the dims after time: its ``[O, T]`` bytes are dense."""
     st = m.stride()
@@ -741,7 +786,15 @@ def _step_mask(m: torch.Tensor, shape, td: int) -> bool:
 
 
 def _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, terminated, eps, algo=ALGO_AUTO, time_dim=-2):
-    """``(advantage, value_target)`` through the fast path (``eps`` not None: normalised advantage), or None."""
+    """``(advantage, value_target)`` through the fast path (``eps`` not None: normalised advantage), or None.
+    With lib/_trl_host.so built the whole of it -- checks, output allocation, C-ABI call -- is one C++ call
+    (csrc/host_fast.cpp); the python below is the same route for a tree without that module."""
+    host = _HOST if _HOST_TRIED else _host_module()
+    if host is not None:
+        out = host.gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, eps, algo, time_dim)
+        if out.__class__ is int:
+            _extension.check(out, _extension.get_lib())
+        return out
     if type(gamma) is not float or type(lmbda) is not float:
         return None
     if terminated is None:
@@ -762,7 +815,7 @@ def _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, termina
         return None
     nd = len(shape)
     td = time_dim + nd if time_dim < 0 else time_dim
-    if not 0 <= td < nd - 1:
+    if not 0 <= td < nd:
         return None
     bcast = 0
     if not (done.is_contiguous() and terminated.is_contiguous()):
