@@ -193,6 +193,10 @@ struct VtraceBwdOp {
     typedef VtraceBwdArgs Args;
     static constexpr int V = V_;
     static constexpr bool kNeedsNext = true, kShifted = false, kReversed = true, kCustomEmit = true;
+    // scan_impl.h: OpPrefetch*.  Two sets of the 10 input arrays spill in the 1024-thread short kernel; in the long kernel
+    // (256-thread blocks) fp32 gains more from the fourth wave per SIMD than from the prefetch, fp64 the other way round
+    // (C5 fp32 135 -> 114 us, fp64 261 with vs 325 without; C4 fp32 34 -> 23 us together with V = 2, fp64 99 -> 60).
+    static constexpr bool kPrefetchShort = false, kPrefetchLong = sizeof(TS_) == 8;
     typedef TS TO;
     static constexpr int kNumOut = 1;
     struct Raw {
@@ -225,14 +229,21 @@ struct VtraceBwdOp {
         w.vs_x = has ? ((const TC *)a.vs)[m] : (TC)0;
         w.v_x = has ? ((const TS *)a.value)[m] : (TS)0;
     }
-    TC A[V], S[V], vs[V], dvsp[V], coef[V];
+    // Register diet (10 arrays of V instead of 14: the 1024-thread short kernel has 128 VGPRs per lane): gamma*nt, gamma*nd,
+    // d vsp and the scan coefficient are re-formed from g, the mask bits, rb and cb where they are used -- same expressions,
+    // same roundings.
+    TC A[V], S[V], vs[V];
     TS v[V], nv[V], r[V], rho[V], rb[V], cb[V];
-    TG gnd[V], gnt[V];
+    TG g[V];
     u8 pass;  // bit e: rho_e <= rho_thresh; bit V + e: rho_e <= c_thresh
     u8 ntm, ndm;
     TC vs_x;
     TS v_x;
     unsigned u0;
+    __device__ __forceinline__ TG gnt(int e) const { return g[e] * (TG)((ntm >> e) & 1); }
+    __device__ __forceinline__ TG gnd(int e) const { return g[e] * (TG)((ndm >> e) & 1); }
+    __device__ __forceinline__ TC dvsp(int e) const { return A[e] * (TC)rb[e] * (TC)gnt(e); }
+    __device__ __forceinline__ TC coef(int e) const { return (TC)gnd(e) * (TC)cb[e]; }
     __device__ __forceinline__ void prepare(const Args &a, const Raw &w) {
         const TS rho_hi = (TS)a.rho_thresh, c_hi = (TS)a.c_thresh;
         u0 = w.u0;
@@ -246,9 +257,7 @@ struct VtraceBwdOp {
             nv[e] = w.nv[e];
             r[e] = w.r[e];
             vs[e] = w.vs[e];
-            const TG ge = a.gamma_t ? w.g[e] : (TG)a.gamma;
-            gnd[e] = ge * (TG)(w.d[e] ? 0 : 1);
-            gnt[e] = ge * (TG)(w.tm[e] ? 0 : 1);
+            g[e] = a.gamma_t ? w.g[e] : (TG)a.gamma;
             ntm |= (u8)((w.tm[e] ? 0 : 1) << e);
             ndm |= (u8)((w.d[e] ? 0 : 1) << e);
             rho[e] = exp_t(w.lp[e] - w.lmu[e]);
@@ -258,15 +267,13 @@ struct VtraceBwdOp {
             pass |= (u8)((rho[e] <= c_hi ? 1 : 0) << (V + e));
             A[e] = a.g_adv ? w.ga[e] : (TC)0;
             S[e] = a.g_vs ? w.gs[e] : (TC)0;
-            dvsp[e] = A[e] * (TC)rb[e] * (TC)gnt[e];
-            coef[e] = (TC)gnd[e] * (TC)cb[e];
         }
     }
     __device__ __forceinline__ TC init(int) const { return (TC)0; }
-    __device__ __forceinline__ TC step(int e, TC x) const { return dvsp[e] + coef[e] * (S[e] + x); }
-    __device__ __forceinline__ void affine(int e, TC &a, TC &b) const { a = coef[e]; b = dvsp[e] + coef[e] * S[e]; }
+    __device__ __forceinline__ TC step(int e, TC x) const { return dvsp(e) + coef(e) * (S[e] + x); }
+    __device__ __forceinline__ void affine(int e, TC &a, TC &b) const { a = coef(e); b = dvsp(e) + a * S[e]; }
     // d vsp of the lane's first element: what the step before it (in time) adds to its gradient w.r.t. vs
-    __device__ __forceinline__ TS first_value() const { return (TS)dvsp[0]; }
+    __device__ __forceinline__ TS first_value() const { return (TS)dvsp(0); }
     template <bool VEC>
     __device__ __forceinline__ void emit(const Args &a, i64 flat, int nvalid, const TC (&xs)[V], const bool (&row_end)[V], TC x_in,
                                          TS v_next) const {
@@ -283,22 +290,22 @@ struct VtraceBwdOp {
             const TS v_n = e == 0 ? v_x : v[e > 0 ? e - 1 : 0];
             const TC vsp = last_t ? (TC)nv[e] : vs_n;
             const TC x_next = last_t ? (TC)0 : vs_n - (TC)v_n;
-            const TC base_a = ((TC)r[e] + (TC)gnt[e] * vsp) - (TC)v[e];
-            const TC base_x = ((TC)r[e] + (TC)gnt[e] * (TC)nv[e]) - (TC)v[e];
+            const TC base_a = ((TC)r[e] + (TC)gnt(e) * vsp) - (TC)v[e];
+            const TC base_x = ((TC)r[e] + (TC)gnt(e) * (TC)nv[e]) - (TC)v[e];
             const TC d_rb = A[e] * base_a + X * base_x;
-            const TC d_cb = X * x_next * (TC)gnd[e];
+            const TC d_cb = X * x_next * (TC)gnd(e);
             const TC d_rho = (((pass >> e) & 1) ? d_rb : (TC)0) + (((pass >> (V + e)) & 1) ? d_cb : (TC)0);
             const TC d_lp = d_rho * (TC)rho[e];
             const TC w = (A[e] + X) * (TC)rb[e];
-            TC d_nv = X * (TC)rb[e] * (TC)gnt[e];
-            if (last_t) d_nv = d_nv + dvsp[e];
+            TC d_nv = X * (TC)rb[e] * (TC)gnt(e);
+            if (last_t) d_nv = d_nv + dvsp(e);
             dlp[e] = (TS)d_lp;
             dlm[e] = (TS)(-d_lp);
             dr[e] = (TS)w;
             dv[e] = (TS)(st - w);
             dnv[e] = (TS)d_nv;
             dg[e] = (TC)((ntm >> e) & 1) * (TC)rb[e] * (A[e] * vsp + X * (TC)nv[e]) + (TC)((ndm >> e) & 1) * X * x_next * (TC)cb[e];
-            if (e < nvalid) { xp = xs[e]; dprev = dvsp[e]; }
+            if (e < nvalid) { xp = xs[e]; dprev = dvsp(e); }
         }
         const i64 n = a.O * a.T;
         if (a.d_log_pi) store_n_rev<VEC>((TS *)a.d_log_pi, n, flat, nvalid, dlp);
@@ -450,12 +457,25 @@ LaunchResult dispatch_bwd_types(int vdt, int cdt, F &&f) {
 inline bool bwd_grid_ok(i64 nb) { return nb > 0 && nb <= 0x7fffffffLL; }
 
 // SCAN launch of a reversed op: I == 1 only; vector accesses also need O*T % V == 0 (mirror image of an aligned vector)
+template <template <typename, typename, int> class OpT, class Args, typename F>
+LaunchResult dispatch_bwd_scan(int vdt, int cdt, i64 T, F &&f) {
+    if constexpr (std::is_same<Args, VtraceBwdArgs>::value) {
+        // the register-heavy op: fp32 rows that fit a chunk of 2 elements per lane (T <= 512) take V = 2 -- no spills under the
+        // short kernel's 128-VGPR cap, 8-byte accesses (C4 34 -> 23 us); longer rows keep 16-byte accesses
+        if (vdt == 0 && T <= 2 * kTeam) {
+            if (cdt == 0) return f(OpT<float, float, 2>{});
+            if (cdt == 1) return f(OpT<float, double, 2>{});
+        }
+    }
+    return dispatch_scan<OpT, Args>(vdt, cdt, f);
+}
+
 template <template <typename, typename, int> class OpT, class Args, typename... P>
 LaunchResult launch_bwd_scan(hipStream_t s, int vdt, int cdt, const Args &a, void *lb_ws, size_t lb_bytes, const char *base,
                              P... ptrs) {
     if (a.I != 1) return LaunchResult{2, 0, nullptr};
     const bool al = (aligned16(ptrs) && ...);
-    return dispatch_scan<OpT, Args>(vdt, cdt, [&](auto op) {
+    return dispatch_bwd_scan<OpT, Args>(vdt, cdt, a.T, [&](auto op) {
         typedef decltype(op) Op;
         const bool vec_ok = al && (a.O * a.T) % Op::V == 0;
         Plan p = make_plan(a.O, a.T, 1, Op::V, vec_ok, device_cus(), lb_ws ? lb_bytes : 0, false);

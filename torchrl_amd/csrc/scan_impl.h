@@ -47,6 +47,18 @@ struct ScanGeom {
     i64 nchunks;         // SHORT geometry
 };
 
+// An op whose inputs do not fit the register file twice (V-trace backward: 10 arrays of V) can say kPrefetchShort /
+// kPrefetchLong = false: that chunk loop then loads at the top of an iteration instead of holding the next chunk's inputs
+// while this one is scanned.
+template <class Op, class = void>
+struct OpPrefetchShort { static constexpr bool value = true; };
+template <class Op>
+struct OpPrefetchShort<Op, std::void_t<decltype(Op::kPrefetchShort)>> { static constexpr bool value = Op::kPrefetchShort; };
+template <class Op, class = void>
+struct OpPrefetchLong { static constexpr bool value = true; };
+template <class Op>
+struct OpPrefetchLong<Op, std::void_t<decltype(Op::kPrefetchLong)>> { static constexpr bool value = Op::kPrefetchLong; };
+
 __device__ __forceinline__ int clamp_nvalid(int count, int lane_off, int V) {
     const int nv = count - lane_off;
     return nv < 0 ? 0 : (nv > V ? V : nv);
@@ -77,20 +89,22 @@ __global__ __launch_bounds__(kShortThreads) void scan_short_kernel(typename Op::
         count = (int)(nrows * geo.T);
     };
 
+    constexpr bool PF = OpPrefetchShort<Op>::value;
     double s = 0.0, ss = 0.0;
     typename Op::Raw cur, nxt;
     i64 start;
     int count;
     geom_of(0, start, count);
-    load_inputs<Op, VEC>(args, start + lane_off, clamp_nvalid(count, lane_off, V), cur);
+    if (PF) load_inputs<Op, VEC>(args, start + lane_off, clamp_nvalid(count, lane_off, V), cur);
     for (i64 it = 0; it < niter; ++it) {
-        if (it + 1 < niter) {
+        if (PF && it + 1 < niter) {
             i64 nstart;
             int ncount;
             geom_of(it + 1, nstart, ncount);
             load_inputs<Op, VEC>(args, nstart + lane_off, clamp_nvalid(ncount, lane_off, V), nxt);
         }
         geom_of(it, start, count);
+        if (!PF) load_inputs<Op, VEC>(args, start + lane_off, clamp_nvalid(count, lane_off, V), cur);
         const int nvalid = clamp_nvalid(count, lane_off, V);
         const i64 flat = start + lane_off;
         Op op;
@@ -101,7 +115,7 @@ __global__ __launch_bounds__(kShortThreads) void scan_short_kernel(typename Op::
                                    [&](const TC(&xs)[V], const bool(&row_end)[V], TC x_in, TS v_next) {
                                        emit_outputs<Op, VEC>(op, args, flat, nvalid, xs, row_end, x_in, v_next, s, ss);
                                    });
-        cur = nxt;
+        if (PF) cur = nxt;
     }
     if (partials) {
         block_sum2<kShortThreads>(s, ss, red);
@@ -292,8 +306,9 @@ __global__ __launch_bounds__(kLongThreads) void scan_long_kernel(typename Op::Ar
     int buf = 0;
     i64 row = blockIdx.x;
     int c = nchunks - 1;
+    constexpr bool PF = OpPrefetchLong<Op>::value;
     typename Op::Raw cur, nxt;
-    if (row < geo.O)
+    if (PF && row < geo.O)
         load_inputs<Op, VEC>(args, row * geo.T + (i64)c * kChunk + lane_off, clamp_nvalid(chunk_count(c), lane_off, V), cur);
     TC Xc = (TC)0;
     TS Xv = (TS)0;
@@ -301,12 +316,13 @@ __global__ __launch_bounds__(kLongThreads) void scan_long_kernel(typename Op::Ar
         i64 nrow = row;
         int nc = c - 1;
         if (nc < 0) { nrow = row + gridDim.x; nc = nchunks - 1; }
-        if (nrow < geo.O)
+        if (PF && nrow < geo.O)
             load_inputs<Op, VEC>(args, nrow * geo.T + (i64)nc * kChunk + lane_off,
                                    clamp_nvalid(chunk_count(nc), lane_off, V), nxt);
         const i64 start = row * geo.T + (i64)c * kChunk;
         const int nvalid = clamp_nvalid(chunk_count(c), lane_off, V);
         const i64 flat = start + lane_off;
+        if (!PF) load_inputs<Op, VEC>(args, flat, nvalid, cur);
         Op op;
         op.prepare(args, cur);
         scan_chunk<Op, false>(op, sh, buf, nvalid, (unsigned)((i64)c * kChunk + lane_off), T, kWave, Xc, Xv,
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(kLongThreads) void scan_long_kernel(typename Op::Ar
                                   emit_outputs<Op, VEC>(op, args, flat, nvalid, xs, row_end, x_in, v_next, s, ss);
                               });
         buf ^= 1;
-        cur = nxt;
+        if (PF) cur = nxt;
         row = nrow;
         c = nc;
     }
