@@ -157,3 +157,60 @@ def test_gae_fast_path_any_time_dim(shape, time_dim, masks, eps, host, monkeypat
         ref = O.normalize(ra, eps)
         torch.testing.assert_close(adv.cpu(), ref, rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(vt.cpu(), rvt, **tol(ra.dtype))
+
+
+@pytest.fixture
+def default_dtype(request):
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(request.param)
+    yield request.param
+    torch.set_default_dtype(old)
+
+
+@pytest.mark.parametrize("default_dtype", [torch.float32, torch.float64], ids=["def32", "def64"], indirect=True)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape,time_dim", [((6, 40, 1), -2), ((3, 2500, 1), -2), ((9, 20, 3, 1), -3), ((5, 33), -1)])
+@pytest.mark.parametrize("masks", ["full", "expanded"])
+def test_host_module_and_python_routes_agree(shape, time_dim, masks, dtype, default_dtype, monkeypatch):
+    """csrc/host_fast.cpp makes the same C-ABI call the python host code makes: every estimator it serves, bit for bit and
+    dtype for dtype, under both torch default dtypes (they decide how python-float coefficients are rounded)."""
+    assert F.host_fast_path(), "lib/_trl_host.so is not built (make -C torchrl_amd/csrc)"
+    g = torch.Generator().manual_seed(11)
+    mk = lambda: torch.randn(shape, generator=g, dtype=torch.float32).to(dtype).to(DEV)
+    r, v, nv = mk(), mk(), mk()
+    lp = torch.rand(shape, generator=g).clamp_min(1e-3).log().to(dtype).to(DEV)
+    lm = torch.rand(shape, generator=g).clamp_min(1e-3).log().to(dtype).to(DEV)
+    td = time_dim % len(shape)
+    mshape = shape if masks == "full" else shape[:td + 1] + (1,) * (len(shape) - td - 1)
+    term = (torch.rand(mshape, generator=g) < 0.05).to(DEV)
+    done = (term | (torch.rand(mshape, generator=g) < 0.05).to(DEV)).expand(shape)
+    term = term.expand(shape)
+    calls = {
+        "gae": lambda: F.generalized_advantage_estimate(0.99, 0.95, v, nv, r, done, term, time_dim=time_dim),
+        "vec_gae": lambda: F.vec_generalized_advantage_estimate(0.99, 0.95, v, nv, r, done, term, time_dim=time_dim),
+        "gae_normalized": lambda: F.gae_normalized(0.99, 0.95, v, nv, r, done, term, eps=1e-4, time_dim=time_dim),
+        "td_lambda": lambda: (F.td_lambda_return_estimate(0.99, 0.95, nv, r, done, term, time_dim=time_dim),),
+        "td_lambda_rolling": lambda: (F.td_lambda_return_estimate(0.99, 0.95, nv, r, done, term, True, time_dim=time_dim),),
+        "vec_td_lambda": lambda: (F.vec_td_lambda_return_estimate(0.99, 0.95, nv, r, done, term, False, time_dim=time_dim),),
+        "td_lambda_adv": lambda: (F.td_lambda_advantage_estimate(0.99, 0.95, v, nv, r, done, term, time_dim=time_dim),),
+        "vtrace": lambda: F.vtrace_advantage_estimate(0.99, lp, lm, v, nv, r, done, term, time_dim=time_dim),
+        "vtrace_thresh": lambda: F.vtrace_advantage_estimate(0.97, lp, lm, v, nv, r, done, None, 0.8, 1.3, time_dim=time_dim),
+    }
+    fast = {k: fn() for k, fn in calls.items()}
+    monkeypatch.setattr(F, "_HOST", None)
+    for k, fn in calls.items():
+        slow = fn()
+        for a, b in zip(fast[k], slow):
+            assert a.dtype == b.dtype and a.shape == b.shape, k
+            assert torch.equal(a, b), f"{k}: max abs diff {(a - b).abs().max().item()}"
+
+
+def test_host_module_leaves_reference_errors_to_python():
+    x = torch.zeros(2, 5, 1, device=DEV)
+    m = torch.zeros(2, 5, 1, dtype=torch.bool, device=DEV)
+    with pytest.raises(RuntimeError, match="rolling_gamma=False is expected only with time-sensitive"):
+        F.td_lambda_return_estimate(0.99, 0.95, x, x, m, m, False)
+    with pytest.raises(RuntimeError):
+        F.vtrace_advantage_estimate(0.99, x, x, x, x[:1], x, m, m)
+    with pytest.raises(RuntimeError):
+        F.td_lambda_return_estimate(0.99, 0.95, x, x[:, :3], m, m)

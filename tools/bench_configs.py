@@ -83,6 +83,8 @@ def main():
     report("C4 [65536x32] GAE f32", timeit(F.prepare_gae_step(call, normalize=False).run, 4 * it), n, 22)
     report("C4 [65536x32] GAE+normalise f32 (fused)", timeit(F.prepare_gae_step(call, 1e-4, normalize=True).run, 4 * it), n, 22)
     report("C4 [65536x32] GAE+normalise f32 (scan+normalize kernels)", timeit(F.prepare_gae_step(call, 1e-4, normalize=True, algo=F.ALGO_SCAN).run, 4 * it), n, 22)
+    report("C4 [65536x32] TD(lambda) f32", timeit(lambda: F.td_lambda_return_estimate(0.99, 0.95, nv, r, d, t), 4 * it), n, 14)
+    report("C4 [65536x32] V-trace f32", timeit(lambda: F.vtrace_advantage_estimate(0.99, lp, lm, v, nv, r, d, t), 4 * it), n, 30)
     report("C4 [65536x32] GAE f32 SEQ family", timeit(F.prepare_gae_step(call, normalize=False, algo=F.ALGO_SEQ).run, it), n, 22)
     # C5
     shape = (1024, 10000, 1)

@@ -1,16 +1,21 @@
-// Host-side fast path of the GAE entry points (CPython module torchrl_amd.lib._trl_host): the eligibility checks, the two
-// output allocations and the C-ABI call of functional._gae_fast in one C++ function, so that the public
-// generalized_advantage_estimate / vec_generalized_advantage_estimate / gae_normalized cost about the kernel launch itself
-// (drop-in API overhead; measured numbers in DESIGN.md section 5).  Plumbing only: no arithmetic on the data
-// happens here, the kernels are reached through the same trl_gae_fwd / trl_gae_normalize_fwd entry points (include/trl_value.h)
-// whose addresses python hands over at init -- the library this module drives is whichever one ctypes loaded.
+// Host-side fast path of the python entry points (CPython module torchrl_amd/lib/_trl_host.so): the eligibility checks, the
+// output allocations and the C-ABI call in one C++ function, so that generalized_advantage_estimate /
+// vec_generalized_advantage_estimate / gae_normalized / (vec_)td_lambda_return_estimate / vtrace_advantage_estimate cost
+// about the kernel launch itself (drop-in API overhead; measured numbers in DESIGN.md section 5).  Plumbing
+// only: no arithmetic on the data happens here, the kernels are reached through the same entry points of
+// include/trl_value.h, whose addresses python hands over at init -- the library this module drives is whichever one ctypes
+// loaded.
 //
 // gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated|None, eps|None, algo, time_dim)
-//   -> (advantage, value_target)   the call was made
+// td_lambda(gamma, lmbda, next_state_value, reward, done, terminated|None, algo, time_dim)
+// vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward, done, terminated|None, rho_thresh, c_thresh, algo, time_dim)
+//   -> the outputs (tuple / tensor) the call was made
 //   -> None                        not a fast-path call (python's general path takes it and raises the reference's errors)
 //   -> int                         non-zero status of the C-ABI call (python raises TrlError with trl_last_error())
-// Eligible: python-float gamma / lmbda, dense same-shape float32 / float64 tensors on the current HIP device, bool masks either
-// dense or per-step masks expanded (stride 0) over the dims after time, no autograd.
+// Eligible: python-float coefficients / thresholds, dense same-shape float32 / float64 tensors of one dtype on the current HIP
+// device, bool masks either dense or per-step masks expanded (stride 0) over the dims after time, no autograd.  Scalar
+// coefficients are rounded here as functional._scalar_mask_coef / _round_to do (the reference's `gamma * int32_mask` takes
+// the torch default dtype, functional.py:172-174, 1322-1323; torch.full_like(values, gamma) the value dtype, :850-857).
 #include <torch/csrc/autograd/python_variable.h>
 #include <ATen/ATen.h>
 #include <c10/core/GradMode.h>
@@ -23,22 +28,13 @@
 
 namespace {
 
-typedef decltype(&trl_gae_fwd) gae_fwd_fn;
-typedef decltype(&trl_gae_normalize_fwd) gae_norm_fn;
-typedef decltype(&trl_workspace_bytes) ws_bytes_fn;
-
-gae_fwd_fn g_gae_fwd = nullptr;
-gae_norm_fn g_gae_norm = nullptr;
-ws_bytes_fn g_ws_bytes = nullptr;
-PyObject *g_coef_cb = nullptr;    // (gamma, lmbda) -> (gamma as rounded by the reference's mask product, lmbda*gamma likewise, coef dtype code) | None
+decltype(&trl_gae_fwd) g_gae_fwd = nullptr;
+decltype(&trl_gae_normalize_fwd) g_gae_norm = nullptr;
+decltype(&trl_workspace_bytes) g_ws_bytes = nullptr;
+decltype(&trl_td_lambda_fwd) g_td_lambda = nullptr;
+decltype(&trl_vtrace_fwd) g_vtrace = nullptr;
 PyObject *g_ws_cb = nullptr;      // (device index, O, T, I) -> None; python allocates / grows the workspace and calls set_workspace
 PyObject *g_stream_cb = nullptr;  // torch._C._cuda_getCurrentRawStream
-
-struct Coef {
-    double gamma, lmbda, g_val, lg_val;
-    int default_dtype, cdt;
-};
-Coef g_coef = {0, 0, 0, 0, -1, 0};
 
 struct Workspace {
     int dev;
@@ -68,18 +64,134 @@ bool dense_after_expand(const at::Tensor &m, c10::IntArrayRef shape, int64_t td)
     return true;
 }
 
+// What every estimator's fast path checks: `vals` dense, same shape / dtype / device; masks bool, dense or expanded per-step.
+struct Call {
+    int64_t O, T, I;
+    int bcast, vdt;
+    int dev;
+    uintptr_t stream;
+    at::ScalarType dt;
+};
+enum Status { kOk, kDecline, kError };
+
+Status canonical(const at::Tensor *const *vals, int nvals, const at::Tensor &done, const at::Tensor &term, int64_t td, Call &c) {
+    const at::Tensor &ref = *vals[0];
+    auto shape = ref.sizes();
+    const int64_t nd = (int64_t)shape.size();
+    if (nd < 2 || done.sizes() != shape || term.sizes() != shape) return kDecline;
+    const auto dt = ref.scalar_type();
+    if ((dt != at::kFloat && dt != at::kDouble) || done.scalar_type() != at::kBool || term.scalar_type() != at::kBool) return kDecline;
+    const auto dev = ref.device();
+    if (!dev.is_cuda() || done.device() != dev || term.device() != dev) return kDecline;
+    bool grad = false;
+    for (int k = 0; k < nvals; ++k) {
+        const at::Tensor &t = *vals[k];
+        if (t.sizes() != shape || t.scalar_type() != dt || t.device() != dev || !t.is_contiguous()) return kDecline;
+        grad = grad || t.requires_grad();
+    }
+    if (grad && c10::GradMode::is_enabled()) return kDecline;
+    if (c10::impl::getDeviceGuardImpl(c10::DeviceType::CUDA)->getDevice().index() != dev.index()) return kDecline;
+    if (td < 0) td += nd;
+    if (td < 0 || td >= nd) return kDecline;
+    c.bcast = 0;
+    if (!done.is_contiguous() || !term.is_contiguous()) {
+        if (!dense_after_expand(done, shape, td) || !dense_after_expand(term, shape, td)) return kDecline;
+        c.bcast = 1;
+    }
+    const int64_t n = ref.numel();
+    if (n == 0) return kDecline;
+    c.T = shape[td];
+    c.I = 1;
+    for (int64_t k = td + 1; k < nd; ++k) c.I *= shape[k];
+    c.O = n / (c.T * c.I);
+    c.dt = dt;
+    c.vdt = dt == at::kFloat ? TRL_F32 : TRL_F64;
+    c.dev = dev.index();
+    PyObject *dev_idx = PyLong_FromLong(c.dev);
+    PyObject *sres = PyObject_CallFunctionObjArgs(g_stream_cb, dev_idx, nullptr);
+    Py_DECREF(dev_idx);
+    if (!sres) return kError;
+    c.stream = (uintptr_t)PyLong_AsUnsignedLongLong(sres);
+    Py_DECREF(sres);
+    return PyErr_Occurred() ? kError : kOk;
+}
+
+// double -> the value a python float takes as a tensor of `dt` (round to nearest even; beyond FLT_MAX: inf, as torch)
+bool round_to(double x, at::ScalarType dt, double &out) {
+    if (dt == at::kDouble) { out = x; return true; }
+    if (dt == at::kFloat) { out = (double)(float)x; return true; }
+    return false;
+}
+
+// the (device, stream) workspace when the call needs one: `always` (normalising call), else only for the look-back scan of few,
+// very long rows (functional._lookback_workspace)
+Status workspace_for(const Call &c, bool always, uintptr_t &ptr, size_t &bytes) {
+    ptr = 0;
+    bytes = 0;
+    if (!always && !(c.I == 1 && c.T >= 2048 && c.O < 4096)) return kOk;
+    const size_t need = g_ws_bytes(c.O, c.T, c.I);
+    Workspace *w = find_ws(c.dev, c.stream);
+    if (!w || w->bytes < need) {
+        PyObject *res = PyObject_CallFunction(g_ws_cb, "iLLL", c.dev, (long long)c.O, (long long)c.T, (long long)c.I);
+        if (!res) return kError;
+        Py_DECREF(res);
+        w = find_ws(c.dev, c.stream);
+        if (!w || w->bytes < need) {
+            PyErr_SetString(PyExc_RuntimeError, "_trl_host: workspace callback did not register a large enough workspace");
+            return kError;
+        }
+    }
+    ptr = w->ptr;
+    bytes = w->bytes;
+    return kOk;
+}
+
+bool empty_like(const at::Tensor &ref, at::ScalarType dt, at::Tensor &out) {
+    try {
+        out = dt == ref.scalar_type() ? at::empty_like(ref) : at::empty_like(ref, ref.options().dtype(dt));
+        return true;
+    } catch (const std::exception &e) {
+        PyErr_SetString(PyExc_RuntimeError, e.what());
+        return false;
+    }
+}
+
+PyObject *pair(at::Tensor &&a, at::Tensor &&b) {
+    PyObject *out = PyTuple_New(2);
+    if (!out) return nullptr;
+    PyTuple_SET_ITEM(out, 0, THPVariable_Wrap(std::move(a)));
+    PyTuple_SET_ITEM(out, 1, THPVariable_Wrap(std::move(b)));
+    return out;
+}
+
+bool ready(Py_ssize_t nargs, Py_ssize_t want, const char *name) {
+    if (nargs != want) {
+        PyErr_Format(PyExc_TypeError, "_trl_host.%s takes %zd positional arguments", name, want);
+        return false;
+    }
+    if (!g_gae_fwd) {
+        PyErr_SetString(PyExc_RuntimeError, "_trl_host called before init");
+        return false;
+    }
+    return true;
+}
+
 PyObject *py_init(PyObject *, PyObject *args) {
-    unsigned long long a, b, c;
-    PyObject *coef_cb, *ws_cb, *stream_cb;
-    if (!PyArg_ParseTuple(args, "KKKOOO", &a, &b, &c, &coef_cb, &ws_cb, &stream_cb)) return nullptr;
-    g_gae_fwd = (gae_fwd_fn)(uintptr_t)a;
-    g_gae_norm = (gae_norm_fn)(uintptr_t)b;
-    g_ws_bytes = (ws_bytes_fn)(uintptr_t)c;
-    Py_XDECREF(g_coef_cb); Py_XDECREF(g_ws_cb); Py_XDECREF(g_stream_cb);
-    Py_INCREF(coef_cb); Py_INCREF(ws_cb); Py_INCREF(stream_cb);
-    g_coef_cb = coef_cb; g_ws_cb = ws_cb; g_stream_cb = stream_cb;
+    unsigned long long a, b, c, d, e;
+    PyObject *ws_cb, *stream_cb;
+    if (!PyArg_ParseTuple(args, "KKKKKOO", &a, &b, &c, &d, &e, &ws_cb, &stream_cb)) return nullptr;
+    g_gae_fwd = (decltype(g_gae_fwd))(uintptr_t)a;
+    g_gae_norm = (decltype(g_gae_norm))(uintptr_t)b;
+    g_ws_bytes = (decltype(g_ws_bytes))(uintptr_t)c;
+    g_td_lambda = (decltype(g_td_lambda))(uintptr_t)d;
+    g_vtrace = (decltype(g_vtrace))(uintptr_t)e;
+    Py_XDECREF(g_ws_cb);
+    Py_XDECREF(g_stream_cb);
+    Py_INCREF(ws_cb);
+    Py_INCREF(stream_cb);
+    g_ws_cb = ws_cb;
+    g_stream_cb = stream_cb;
     g_ws.clear();
-    g_coef.default_dtype = -1;
     Py_RETURN_NONE;
 }
 
@@ -97,20 +209,15 @@ PyObject *py_set_workspace(PyObject *, PyObject *args) {
     Py_RETURN_NONE;
 }
 
+#define DECLINE_UNLESS_TENSOR(obj) \
+    if (!THPVariable_Check(obj)) Py_RETURN_NONE
+
 PyObject *py_gae(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
-    if (nargs != 10) {
-        PyErr_SetString(PyExc_TypeError, "_trl_host.gae takes 10 positional arguments");
-        return nullptr;
-    }
-    if (!g_gae_fwd) {
-        PyErr_SetString(PyExc_RuntimeError, "_trl_host.gae called before init");
-        return nullptr;
-    }
+    if (!ready(nargs, 10, "gae")) return nullptr;
     if (!PyFloat_CheckExact(a[0]) || !PyFloat_CheckExact(a[1])) Py_RETURN_NONE;
-    for (int k = 2; k <= 5; ++k)
-        if (!THPVariable_Check(a[k])) Py_RETURN_NONE;
+    for (int k = 2; k <= 5; ++k) DECLINE_UNLESS_TENSOR(a[k]);
     const bool has_term = a[6] != Py_None;
-    if (has_term && !THPVariable_Check(a[6])) Py_RETURN_NONE;
+    if (has_term) DECLINE_UNLESS_TENSOR(a[6]);
     const at::Tensor &sv = THPVariable_Unpack(a[2]);
     const at::Tensor &nsv = THPVariable_Unpack(a[3]);
     const at::Tensor &r = THPVariable_Unpack(a[4]);
@@ -119,114 +226,134 @@ PyObject *py_gae(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
     const bool normalise = a[7] != Py_None;
     const double eps = normalise ? PyFloat_AsDouble(a[7]) : 0.0;
     const long algo = PyLong_AsLong(a[8]);
-    int64_t td = PyLong_AsLongLong(a[9]);
+    const int64_t td = PyLong_AsLongLong(a[9]);
     if (PyErr_Occurred()) return nullptr;
 
-    auto shape = nsv.sizes();
-    const int64_t nd = (int64_t)shape.size();
-    if (nd < 2 || sv.sizes() != shape || r.sizes() != shape || done.sizes() != shape || term.sizes() != shape) Py_RETURN_NONE;
-    const auto dt = nsv.scalar_type();
-    if ((dt != at::kFloat && dt != at::kDouble) || sv.scalar_type() != dt || r.scalar_type() != dt || done.scalar_type() != at::kBool ||
-        term.scalar_type() != at::kBool)
+    // gamma * int32_mask and (lmbda * gamma) * int32_mask: both take the default dtype (functional.py:172-174)
+    const auto ddt = c10::get_default_dtype_as_scalartype();
+    double g_val, lg_val;
+    if (!round_to(PyFloat_AS_DOUBLE(a[0]), ddt, g_val) || !round_to(PyFloat_AS_DOUBLE(a[1]) * PyFloat_AS_DOUBLE(a[0]), ddt, lg_val))
         Py_RETURN_NONE;
-    const auto dev = nsv.device();
-    if (!dev.is_cuda() || sv.device() != dev || r.device() != dev || done.device() != dev || term.device() != dev) Py_RETURN_NONE;
-    if (c10::impl::getDeviceGuardImpl(c10::DeviceType::CUDA)->getDevice().index() != dev.index()) Py_RETURN_NONE;
-    if (!nsv.is_contiguous() || !sv.is_contiguous() || !r.is_contiguous()) Py_RETURN_NONE;
-    if (td < 0) td += nd;
-    if (td < 0 || td >= nd) Py_RETURN_NONE;
-    int bcast = 0;
-    if (!done.is_contiguous() || !term.is_contiguous()) {
-        if (!dense_after_expand(done, shape, td) || !dense_after_expand(term, shape, td)) Py_RETURN_NONE;
-        bcast = 1;
+    const int cdt = ddt == at::kFloat ? TRL_F32 : TRL_F64;
+
+    const at::Tensor *vals[3] = {&nsv, &sv, &r};
+    Call c;
+    switch (canonical(vals, 3, done, term, td, c)) {
+        case kDecline: Py_RETURN_NONE;
+        case kError: return nullptr;
+        default: break;
     }
-    if (c10::GradMode::is_enabled() && (nsv.requires_grad() || sv.requires_grad() || r.requires_grad())) Py_RETURN_NONE;
-    const int64_t n = nsv.numel();
-    if (n == 0) Py_RETURN_NONE;
-    const int64_t T = shape[td];
-    int64_t I = 1;
-    for (int64_t k = td + 1; k < nd; ++k) I *= shape[k];
-    const int64_t O = n / (T * I);
-
-    // coefficients as the reference's int32-mask products round them (python owns that rule; one-entry cache)
-    const double gamma = PyFloat_AS_DOUBLE(a[0]), lmbda = PyFloat_AS_DOUBLE(a[1]);
-    const int ddt = (int)c10::get_default_dtype_as_scalartype();
-    if (g_coef.default_dtype != ddt || g_coef.gamma != gamma || g_coef.lmbda != lmbda) {
-        PyObject *res = PyObject_CallFunctionObjArgs(g_coef_cb, a[0], a[1], nullptr);
-        if (!res) return nullptr;
-        if (res == Py_None) return res;
-        double gv, lgv;
-        int cdt;
-        if (!PyArg_ParseTuple(res, "ddi", &gv, &lgv, &cdt)) {
-            Py_DECREF(res);
-            return nullptr;
-        }
-        Py_DECREF(res);
-        g_coef = {gamma, lmbda, gv, lgv, ddt, cdt};
-    }
-
-    PyObject *dev_idx = PyLong_FromLong(dev.index());
-    PyObject *sres = PyObject_CallFunctionObjArgs(g_stream_cb, dev_idx, nullptr);
-    Py_DECREF(dev_idx);
-    if (!sres) return nullptr;
-    const uintptr_t stream = (uintptr_t)PyLong_AsUnsignedLongLong(sres);
-    Py_DECREF(sres);
-    if (PyErr_Occurred()) return nullptr;
-
-    // workspace: the normalising call always has one; the plain call only for the look-back scan of few, very long rows
-    uintptr_t ws_ptr = 0;
-    size_t ws_bytes = 0;
-    if (normalise || (I == 1 && T >= 2048 && O < 4096)) {
-        const size_t need = g_ws_bytes(O, T, I);
-        Workspace *w = find_ws(dev.index(), stream);
-        if (!w || w->bytes < need) {
-            PyObject *res = PyObject_CallFunction(g_ws_cb, "iLLL", (int)dev.index(), (long long)O, (long long)T, (long long)I);
-            if (!res) return nullptr;
-            Py_DECREF(res);
-            w = find_ws(dev.index(), stream);
-            if (!w || w->bytes < need) {
-                PyErr_SetString(PyExc_RuntimeError, "_trl_host: workspace callback did not register a large enough workspace");
-                return nullptr;
-            }
-        }
-        ws_ptr = w->ptr;
-        ws_bytes = w->bytes;
-    }
-
+    uintptr_t ws_ptr;
+    size_t ws_bytes;
+    if (workspace_for(c, normalise, ws_ptr, ws_bytes) != kOk) return nullptr;
     at::Tensor adv, vt;
-    try {
-        adv = at::empty_like(nsv);
-        vt = at::empty_like(nsv);
-    } catch (const std::exception &e) {
-        PyErr_SetString(PyExc_RuntimeError, e.what());
-        return nullptr;
-    }
-    const int vdt = dt == at::kFloat ? TRL_F32 : TRL_F64;
+    if (!empty_like(nsv, c.dt, adv) || !empty_like(nsv, c.dt, vt)) return nullptr;
     int rc;
     if (normalise)
-        rc = g_gae_norm((void *)stream, vdt, g_coef.cdt, r.data_ptr(), sv.data_ptr(), nsv.data_ptr(), (const uint8_t *)done.data_ptr(),
-                        (const uint8_t *)term.data_ptr(), bcast, nullptr, nullptr, g_coef.g_val, 0.0, g_coef.lg_val, O, T, I,
-                        adv.data_ptr(), vt.data_ptr(), eps, nullptr, (void *)ws_ptr, ws_bytes, (int)algo);
+        rc = g_gae_norm((void *)c.stream, c.vdt, cdt, r.data_ptr(), sv.data_ptr(), nsv.data_ptr(), (const uint8_t *)done.data_ptr(),
+                        (const uint8_t *)term.data_ptr(), c.bcast, nullptr, nullptr, g_val, 0.0, lg_val, c.O, c.T, c.I, adv.data_ptr(),
+                        vt.data_ptr(), eps, nullptr, (void *)ws_ptr, ws_bytes, (int)algo);
     else
-        rc = g_gae_fwd((void *)stream, vdt, g_coef.cdt, r.data_ptr(), sv.data_ptr(), nsv.data_ptr(), (const uint8_t *)done.data_ptr(),
-                       (const uint8_t *)term.data_ptr(), bcast, nullptr, nullptr, g_coef.g_val, 0.0, g_coef.lg_val, O, T, I,
-                       adv.data_ptr(), vt.data_ptr(), nullptr, (void *)ws_ptr, ws_bytes, (int)algo);
+        rc = g_gae_fwd((void *)c.stream, c.vdt, cdt, r.data_ptr(), sv.data_ptr(), nsv.data_ptr(), (const uint8_t *)done.data_ptr(),
+                       (const uint8_t *)term.data_ptr(), c.bcast, nullptr, nullptr, g_val, 0.0, lg_val, c.O, c.T, c.I, adv.data_ptr(),
+                       vt.data_ptr(), nullptr, (void *)ws_ptr, ws_bytes, (int)algo);
     if (rc) return PyLong_FromLong(rc);
-    PyObject *out = PyTuple_New(2);
-    if (!out) return nullptr;
-    PyTuple_SET_ITEM(out, 0, THPVariable_Wrap(std::move(adv)));
-    PyTuple_SET_ITEM(out, 1, THPVariable_Wrap(std::move(vt)));
-    return out;
+    return pair(std::move(adv), std::move(vt));
+}
+
+PyObject *py_td_lambda(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
+    if (!ready(nargs, 8, "td_lambda")) return nullptr;
+    if (!PyFloat_CheckExact(a[0]) || !PyFloat_CheckExact(a[1])) Py_RETURN_NONE;
+    for (int k = 2; k <= 4; ++k) DECLINE_UNLESS_TENSOR(a[k]);
+    const bool has_term = a[5] != Py_None;
+    if (has_term) DECLINE_UNLESS_TENSOR(a[5]);
+    const at::Tensor &nsv = THPVariable_Unpack(a[2]);
+    const at::Tensor &r = THPVariable_Unpack(a[3]);
+    const at::Tensor &done = THPVariable_Unpack(a[4]);
+    const at::Tensor &term = has_term ? THPVariable_Unpack(a[5]) : done;
+    const long algo = PyLong_AsLong(a[6]);
+    const int64_t td = PyLong_AsLongLong(a[7]);
+    if (PyErr_Occurred()) return nullptr;
+    const at::Tensor *vals[2] = {&nsv, &r};
+    Call c;
+    switch (canonical(vals, 2, done, term, td, c)) {
+        case kDecline: Py_RETURN_NONE;
+        case kError: return nullptr;
+        default: break;
+    }
+    // torch.full_like(next_state_value, gamma): scalar coefficients take the value dtype (functional.py:850-857)
+    double g_val = 0.0, l_val = 0.0;
+    round_to(PyFloat_AS_DOUBLE(a[0]), c.dt, g_val);
+    round_to(PyFloat_AS_DOUBLE(a[1]), c.dt, l_val);
+    uintptr_t ws_ptr;
+    size_t ws_bytes;
+    if (workspace_for(c, false, ws_ptr, ws_bytes) != kOk) return nullptr;
+    at::Tensor out;
+    if (!empty_like(nsv, c.dt, out)) return nullptr;
+    const int rc = g_td_lambda((void *)c.stream, c.vdt, c.vdt, r.data_ptr(), nsv.data_ptr(), (const uint8_t *)done.data_ptr(),
+                               (const uint8_t *)term.data_ptr(), c.bcast, nullptr, nullptr, g_val, l_val, 1, c.O, c.T, c.I, out.data_ptr(),
+                               (void *)ws_ptr, ws_bytes, (int)algo);
+    if (rc) return PyLong_FromLong(rc);
+    return THPVariable_Wrap(std::move(out));
+}
+
+PyObject *py_vtrace(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
+    if (!ready(nargs, 12, "vtrace")) return nullptr;
+    if (!PyFloat_CheckExact(a[0]) || !PyFloat_CheckExact(a[8]) || !PyFloat_CheckExact(a[9])) Py_RETURN_NONE;
+    for (int k = 1; k <= 6; ++k) DECLINE_UNLESS_TENSOR(a[k]);
+    const bool has_term = a[7] != Py_None;
+    if (has_term) DECLINE_UNLESS_TENSOR(a[7]);
+    const at::Tensor &lp = THPVariable_Unpack(a[1]);
+    const at::Tensor &lmu = THPVariable_Unpack(a[2]);
+    const at::Tensor &sv = THPVariable_Unpack(a[3]);
+    const at::Tensor &nsv = THPVariable_Unpack(a[4]);
+    const at::Tensor &r = THPVariable_Unpack(a[5]);
+    const at::Tensor &done = THPVariable_Unpack(a[6]);
+    const at::Tensor &term = has_term ? THPVariable_Unpack(a[7]) : done;
+    const long algo = PyLong_AsLong(a[10]);
+    const int64_t td = PyLong_AsLongLong(a[11]);
+    if (PyErr_Occurred()) return nullptr;
+    // gamma * int32_mask takes the default dtype; python thresholds become 0-dim default-dtype tensors (functional.py:1311-1323)
+    const auto ddt = c10::get_default_dtype_as_scalartype();
+    double g_val, rho_hi, c_hi;
+    if (!round_to(PyFloat_AS_DOUBLE(a[0]), ddt, g_val) || !round_to(PyFloat_AS_DOUBLE(a[8]), ddt, rho_hi) ||
+        !round_to(PyFloat_AS_DOUBLE(a[9]), ddt, c_hi))
+        Py_RETURN_NONE;
+    const int cdt = ddt == at::kFloat ? TRL_F32 : TRL_F64;
+    const at::Tensor *vals[5] = {&nsv, &sv, &r, &lp, &lmu};
+    Call c;
+    switch (canonical(vals, 5, done, term, td, c)) {
+        case kDecline: Py_RETURN_NONE;
+        case kError: return nullptr;
+        default: break;
+    }
+    uintptr_t ws_ptr;
+    size_t ws_bytes;
+    if (workspace_for(c, false, ws_ptr, ws_bytes) != kOk) return nullptr;
+    const auto odt = (c.dt == at::kDouble || ddt == at::kDouble) ? at::kDouble : at::kFloat;  // promote(value, coefficient dtype)
+    at::Tensor adv, vs;
+    if (!empty_like(nsv, odt, adv) || !empty_like(nsv, odt, vs)) return nullptr;
+    const int rc = g_vtrace((void *)c.stream, c.vdt, cdt, lp.data_ptr(), lmu.data_ptr(), sv.data_ptr(), nsv.data_ptr(), r.data_ptr(),
+                            (const uint8_t *)done.data_ptr(), (const uint8_t *)term.data_ptr(), c.bcast, nullptr, g_val, rho_hi, c_hi,
+                            nullptr, nullptr, c.O, c.T, c.I, adv.data_ptr(), vs.data_ptr(), (void *)ws_ptr, ws_bytes, (int)algo);
+    if (rc) return PyLong_FromLong(rc);
+    return pair(std::move(adv), std::move(vs));
 }
 
 PyMethodDef methods[] = {
-    {"init", py_init, METH_VARARGS, "init(trl_gae_fwd, trl_gae_normalize_fwd, trl_workspace_bytes, coef_cb, ws_cb, stream_cb)"},
+    {"init", py_init, METH_VARARGS,
+     "init(trl_gae_fwd, trl_gae_normalize_fwd, trl_workspace_bytes, trl_td_lambda_fwd, trl_vtrace_fwd, ws_cb, stream_cb)"},
     {"set_workspace", py_set_workspace, METH_VARARGS, "set_workspace(device index, stream, pointer, bytes)"},
     {"gae", (PyCFunction)(void (*)(void))py_gae, METH_FASTCALL,
      "gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, eps, algo, time_dim)"},
+    {"td_lambda", (PyCFunction)(void (*)(void))py_td_lambda, METH_FASTCALL,
+     "td_lambda(gamma, lmbda, next_state_value, reward, done, terminated, algo, time_dim)"},
+    {"vtrace", (PyCFunction)(void (*)(void))py_vtrace, METH_FASTCALL,
+     "vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward, done, terminated, rho_thresh, c_thresh, algo, time_dim)"},
     {nullptr, nullptr, 0, nullptr}};
 
-PyModuleDef module = {PyModuleDef_HEAD_INIT, "_trl_host", "host-side fast path of the torchrl_amd GAE entry points", -1, methods};
+PyModuleDef module = {PyModuleDef_HEAD_INIT, "_trl_host", "host-side fast path of the torchrl_amd value-estimator entry points", -1,
+                      methods};
 
 }  // namespace
 

@@ -755,7 +755,8 @@ def _host_module():
         if mod is not None:
             lib = _extension.get_lib()
             mod.init(_extension.fn_address(lib.trl_gae_fwd), _extension.fn_address(lib.trl_gae_normalize_fwd),
-                     _extension.fn_address(lib.trl_workspace_bytes), _fast_coef, _host_workspace, torch._C._cuda_getCurrentRawStream)
+                     _extension.fn_address(lib.trl_workspace_bytes), _extension.fn_address(lib.trl_td_lambda_fwd),
+                     _extension.fn_address(lib.trl_vtrace_fwd), _host_workspace, torch._C._cuda_getCurrentRawStream)
             for (di, st), ws in _WORKSPACES.items():
                 mod.set_workspace(di, st, ws.data_ptr(), ws.numel())
             _HOST = mod
@@ -766,8 +767,16 @@ _HOST_TRIED = False
 
 
 def host_fast_path() -> bool:
-    """True when the GAE entry points go through the C++ host module (bench.py reports it beside entry_point_ms)."""
+    """True when the entry points go through the C++ host module (bench.py reports it beside entry_point_ms)."""
     return _host_module() is not None
+
+
+def _host_call(fn, *args):
+    """One call into the host module: its outputs, or None when the call is not a fast-path one."""
+    out = fn(*args)
+    if out.__class__ is int:
+        _extension.check(out, _extension.get_lib())
+    return out
 
 
 def _step_mask(m: torch.Tensor, shape, td: int) -> bool:
@@ -1241,6 +1250,11 @@ def td_lambda_return_estimate(
         (g, gt), (l, lt) = _ops._split(gamma), _ops._split(lmbda)
         return _ops.td_lambda_op(next_state_value, reward, done, done if terminated is None else terminated, g, l, gt, lt,
                                  -1 if rolling_gamma is None else int(bool(rolling_gamma)), time_dim, False)
+    host = _HOST if _HOST_TRIED else _host_module()
+    if host is not None and (rolling_gamma is None or rolling_gamma):
+        out = _host_call(host.td_lambda, gamma, lmbda, next_state_value, reward, done, terminated, ALGO_AUTO, time_dim)
+        if out is not None:
+            return out
     call = _prepare_td_lambda(gamma, lmbda, next_state_value, reward, done, terminated, rolling_gamma, time_dim)
     if _needs_grad(next_state_value, reward, gamma, lmbda):
         return _TdLambdaFunction.apply(next_state_value, reward, _coef_leaf(gamma, call.shape, time_dim),
@@ -1267,6 +1281,11 @@ def vec_td_lambda_return_estimate(
         (g, gt), (l, lt) = _ops._split(gamma), _ops._split(lmbda)
         return _ops.td_lambda_op(next_state_value, reward, done, done if terminated is None else terminated, g, l, gt, lt,
                                  -1 if rolling_gamma is None else int(bool(rolling_gamma)), time_dim, True)
+    host = _HOST if _HOST_TRIED else _host_module()
+    if host is not None:   # python-float coefficients: the reference's scalar path ignores rolling_gamma (functional.py:1101-1110)
+        out = _host_call(host.td_lambda, gamma, lmbda, next_state_value, reward, done, terminated, ALGO_AUTO, time_dim)
+        if out is not None:
+            return out
     if terminated is None:
         terminated = done
     if not (next_state_value.shape == reward.shape == done.shape == terminated.shape):
@@ -1472,6 +1491,12 @@ def vtrace_advantage_estimate(
         (g, gt), (rs, rt), (cs, ct) = _ops._split(gamma), _ops._split(rho_thresh), _ops._split(c_thresh)
         return _ops.vtrace_op(log_pi, log_mu, state_value, next_state_value, reward, done, done if terminated is None else terminated,
                               g, gt, rs, cs, rt, ct, time_dim)
+    host = _HOST if _HOST_TRIED else _host_module()
+    if host is not None:
+        out = _host_call(host.vtrace, gamma, log_pi, log_mu, state_value, next_state_value, reward, done, terminated, rho_thresh,
+                         c_thresh, ALGO_AUTO, time_dim)
+        if out is not None:
+            return out
     call = _prepare_vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward, done, terminated,
                            rho_thresh, c_thresh, time_dim)
     if _needs_grad(log_pi, log_mu, state_value, next_state_value, reward, gamma):
