@@ -79,8 +79,9 @@ const char *trl_last_kernel(void);
 size_t trl_workspace_bytes(int64_t O, int64_t T, int64_t I);
 /* 1 if a single-launch (FUSED) call on this workspace ever gave up waiting for its other blocks (its
  * grid of #CUs persistent blocks must be co-resident: a GPU shared with other long-running kernels
- * can starve it; the wait is bounded at 1 s and the outputs are then NaN), 0 if not, -1 on error.
- * Synchronises the device. */
+ * can starve it; the wait is bounded at 1 s, the advantage is then written UN-NORMALISED -- finite, never
+ * NaN -- and the next estimator call of this process returns TRL_ERR_LAUNCH without a sync), 0 if not, -1 on
+ * error.  Synchronises the device. */
 int trl_workspace_error(const void *workspace);
 
 /*
@@ -347,7 +348,10 @@ int trl_standardize_grouped(void *stream, int dtype, const void *x, int64_t oute
  *                                              ranks (fixed rank order), N exact.  Asynchronous;
  *                                              graph-capturable (the call counter lives on the device).
  * A rank that waits longer than timeout_s (default 20) for a peer sets the comm's error word and
- * writes NaNs: trl_xchg_error(comm) (synchronises the device) returns 1.
+ * trl_xchg_allreduce_stats leaves NaN statistics: trl_xchg_error(comm) (synchronises the device) returns 1.
+ * In trl_gae_normalize_xchg_fwd's single launch a rank whose own gather gave up sends NaN moments, so every
+ * rank sees the failure; each then writes the UN-NORMALISED advantage, sets its error words and raises the
+ * host flag (the next estimator call returns TRL_ERR_LAUNCH), as trl_gae_normalize_fwd does on one GPU.
  * trl_gae_normalize_xchg_fwd = trl_gae_normalize_fwd on a batch sharded over the comm's ranks: the
  * moments are summed over all ranks INSIDE the launch (FUSED family: after the in-launch gather of
  * the block moments, block 0 stores this GPU's totals into the peers' mailboxes and every block

@@ -346,7 +346,8 @@ def _workspace(lib, dev, O, T, I):
 
 def workspace_error(device=None) -> bool:
     """True if a single-launch GAE + normalise on ``device``'s current stream ever timed out waiting for its
-    other blocks (the persistent grid needs the whole GPU; outputs of such a call are NaN).  Synchronises."""
+    other blocks (the persistent grid needs the whole GPU; such a call leaves the advantage un-normalised and the next
+    estimator call raises TrlError).  Synchronises."""
     lib = _extension.get_lib()
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     ws = _WORKSPACES.get((dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev)))
