@@ -255,3 +255,57 @@ def test_vtrace_gradient_to_broadcast_log_probs():
     for a, b in zip(got, want):
         assert a.shape == b.shape
         torch.testing.assert_close(a, b, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("layout", ["expanded_masks_I3", "shifted_values"])
+def test_only_gamma_requires_grad_with_compact_layouts(dtype, layout):
+    """with ONLY a gamma tensor requiring grad the forward call must not keep a layout the backward
+    cannot use -- stride-0 masks expanded over I > 1 (compact mask_bcast form) or state_value / next_state_value as the two
+    windows of one [B, T + 1] buffer (shifted form, next_value = None).  GAE, TD(lambda) and V-trace."""
+    g = torch.Generator().manual_seed(21)
+    if layout == "expanded_masks_I3":
+        shape = (5, 20, 3)
+        mk = lambda: torch.randn(shape, generator=g, dtype=torch.float64).to(dtype).to(DEV)
+        v, nv = mk(), mk()
+        term = (torch.rand(5, 20, 1, generator=g) < 0.05).to(DEV)
+        done = (term | (torch.rand(5, 20, 1, generator=g) < 0.05).to(DEV)).expand(shape)
+        term = term.expand(shape)
+        assert done.stride()[-1] == 0
+    else:
+        shape = (6, 33, 1)
+        buf = torch.randn(6, 34, 1, generator=g, dtype=torch.float64).to(dtype).to(DEV)
+        v, nv = buf[:, :-1], buf[:, 1:]      # views of one buffer: what shifted=True estimators hand over
+        term = (torch.rand(shape, generator=g) < 0.05).to(DEV)
+        done = term | (torch.rand(shape, generator=g) < 0.05).to(DEV)
+    r = torch.randn(shape, generator=g, dtype=torch.float64).to(dtype).to(DEV)
+    lp = (0.5 * torch.randn(shape, generator=g, dtype=torch.float64)).to(dtype).to(DEV)
+    lm = (0.5 * torch.randn(shape, generator=g, dtype=torch.float64)).to(dtype).to(DEV)
+    wa, wv = (torch.randn(shape, generator=g, dtype=torch.float64).to(dtype).to(DEV) for _ in range(2))
+    gam = (0.9 + 0.1 * torch.rand(shape, generator=g, dtype=torch.float64)).to(dtype).to(DEV).requires_grad_(True)
+    tol = dict(rtol=2e-4, atol=2e-3) if dtype == torch.float32 else dict(rtol=1e-9, atol=1e-8)
+    # the restatements above take [rows, T]: bring (B, T, I) to (B*I, T)
+    rows = lambda x: x.detach().movedim(-1, 1).reshape(-1, shape[1])
+    unrows = lambda x: x.reshape(shape[0], shape[2], shape[1]).movedim(1, -1)
+    g2 = gam.detach().double().requires_grad_(True)
+    g2r = g2.movedim(-1, 1).reshape(-1, shape[1])
+    args = [rows(t).double() for t in (v, nv, r)]
+    dn, tm = rows(done), rows(term)
+
+    adv, vt = F.generalized_advantage_estimate(gam, 0.93, v, nv, r, done, term)
+    (got,) = torch.autograd.grad((adv * wa).sum() + (vt * wv).sum(), (gam,))
+    a2, t2 = torch_gae(g2r, 0.93 * g2r, *args, dn, tm)
+    (want,) = torch.autograd.grad((unrows(a2) * wa.double()).sum() + (unrows(t2) * wv.double()).sum(), (g2,))
+    torch.testing.assert_close(got.double(), want, **tol)
+
+    ret = F.td_lambda_return_estimate(gam, 0.93, nv, r, done, term)
+    (got,) = torch.autograd.grad((ret * wa).sum(), (gam,))
+    ret2 = torch_tdl(g2r, 0.93, args[1], args[2], dn, tm)
+    (want,) = torch.autograd.grad((unrows(ret2) * wa.double()).sum(), (g2,))
+    torch.testing.assert_close(got.double(), want, **tol)
+
+    adv, vs = F.vtrace_advantage_estimate(gam, lp, lm, v, nv, r, done, term)
+    (got,) = torch.autograd.grad((adv * wa).sum() + (vs * wv).sum(), (gam,))
+    a2, s2 = torch_vtrace(g2r, rows(lp).double(), rows(lm).double(), *args, dn, tm, 1.0, 1.0)
+    (want,) = torch.autograd.grad((unrows(a2) * wa.double()).sum() + (unrows(s2) * wv.double()).sum(), (g2,))
+    torch.testing.assert_close(got.double(), want, **tol)
