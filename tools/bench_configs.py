@@ -16,8 +16,8 @@ from torchrl_amd.objectives.value import functional as F  # noqa: E402
 DEV = "cuda:0"
 
 
-def timeit(fn, iters):
-    for _ in range(5):
+def timeit(fn, iters, warm=300):
+    for _ in range(warm):   # clock-settle pre-roll: the first few hundred microseconds of work run at a lower clock
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -28,7 +28,10 @@ struct GaePreparedOp {  // what scan_chunk needs of an estimator whose per-step 
 
 // 4 blocks of 4 waves per CU and a grid of exactly that many blocks: with the next chunk's loads in flight a lane holds two
 // sets of raw inputs, which spills at 5+ blocks per CU (measured 16 us at C3), and a grid above the resident set only queues
-// blocks behind the first round (measured: 5/CU 13.9 us, 8/CU 11.1 us, 4/CU 9.8 us).
+// blocks behind the first round (measured: 5/CU 13.9 us, 8/CU 11.1 us, 4/CU 9.8 us).  Two elements per lane (8-byte
+// accesses, 64 VGPRs, 6 - 8 blocks per CU, with or without the prefetch) was measured too: 11.2 - 13.5 us at C3, dropped.
+// PMC at C3: 47 % of the LDS-array cycles are bank conflicts (the row gather walks LDS with a lane stride of V*I = 20 words:
+// 8 of 32 banks), but the LDS array is busy for only 1.85 us per CU of the 9.6 -- latency, not LDS throughput, bounds it.
 #ifndef GIL_WAVES
 #define GIL_WAVES 4
 #endif
@@ -112,10 +115,14 @@ __global__ __launch_bounds__(kTeam, GIL_WAVES) void gae_interleaved_kernel(GaeAr
 
     double s = 0.0, ss = 0.0;
     const i64 niter = (geo.nchunks + gridDim.x - 1) / gridDim.x;
+#ifndef GIL_PREFETCH
+#define GIL_PREFETCH 1
+#endif
     Raw cur, nxt;
-    load_raw(0, cur);
+    if (GIL_PREFETCH) load_raw(0, cur);
     for (i64 it = 0; it < niter; ++it) {
-        if (it + 1 < niter) load_raw(it + 1, nxt);  // the next chunk's loads fly while this one goes through LDS
+        if (GIL_PREFETCH) { if (it + 1 < niter) load_raw(it + 1, nxt); }  // the next chunk's loads fly while this one goes through LDS
+        else load_raw(it, cur);
         i64 row0, start;
         int count;
         geom_of(it, row0, start, count);
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(kTeam, GIL_WAVES) void gae_interleaved_kernel(GaeAr
             store_n<VEC>((TS *)args.value_target, flat, nvalid, vt);
 #endif
         }
-        cur = nxt;
+        if (GIL_PREFETCH) cur = nxt;
     }
     if (partials) {
         block_sum2<kTeam>(s, ss, red);
