@@ -12,6 +12,8 @@ with open(os.path.join(GOLDEN, "manifest.json")) as _f:
     MANIFEST = json.load(_f)
 with open(os.path.join(GOLDEN, "manifest_next.json")) as _f:  # tools/gen_golden_next.py: td0 / td1 / reward2go, gradients, ...
     MANIFEST.update({k: v for k, v in json.load(_f).items() if isinstance(v, list)})
+with open(os.path.join(GOLDEN, "manifest_vec.json")) as _f:   # tools/gen_golden_vec.py: the reference's vec variants beside its loops
+    MANIFEST.update({k: v for k, v in json.load(_f).items() if isinstance(v, list)})
 _npz = {}
 
 

@@ -214,3 +214,32 @@ def test_host_module_leaves_reference_errors_to_python():
         F.vtrace_advantage_estimate(0.99, x, x, x, x[:1], x, m, m)
     with pytest.raises(RuntimeError):
         F.td_lambda_return_estimate(0.99, 0.95, x, x[:, :3], m, m)
+
+
+@pytest.mark.parametrize("meta", G.cases("vec"), ids=G.ids("vec"))
+def test_vec_variants_against_reference_vec_outputs(meta):
+    """The vec_* names run the same exact kernels: against the reference's LOOP outputs at the SCAN bar, against the
+    reference's own VEC outputs (filter truncation and all) at the reference's 1e-4, same dtypes (tools/gen_golden_vec.py).
+    Where the reference's vec path raises on inputs its loop accepts, only the loop outputs pin the case."""
+    a = G.arrays("vec", meta)
+    done, term = G.expand_masks(meta, a)
+    g, l = cu(G.coef(meta, a, "gamma")), cu(G.coef(meta, a, "lmbda"))
+    v, nv, r, done, term = cu(a["state_value"]), cu(a["next_state_value"]), cu(a["reward"]), cu(done), cu(term)
+    kw = G.time_kw(meta)
+    adv, vt = F.generalized_advantage_estimate(g, l, v, nv, r, done, term, **kw)
+    check(adv, a["advantage"], False)
+    check(vt, a["value_target"], False)
+    adv, vt = F.vec_generalized_advantage_estimate(g, l, v, nv, r, done, term, **kw)   # its dtype follows the reference's VEC variant
+    torch.testing.assert_close(adv.cpu().to(a["advantage"].dtype), a["advantage"], **tol(a["advantage"].dtype))
+    torch.testing.assert_close(vt.cpu().to(a["advantage"].dtype), a["value_target"], **tol(a["advantage"].dtype))
+    if "vec_advantage" in a:
+        assert adv.dtype == a["vec_advantage"].dtype
+        torch.testing.assert_close(adv.cpu(), a["vec_advantage"], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(vt.cpu(), a["vec_value_target"], rtol=1e-4, atol=1e-4)
+    ret = F.td_lambda_return_estimate(g, l, nv, r, done, term, **kw)
+    check(ret, a["returns"], False)
+    vret = F.vec_td_lambda_return_estimate(g, l, nv, r, done, term, **kw)
+    if "vec_returns" in a:
+        assert vret.dtype == a["vec_returns"].dtype
+        torch.testing.assert_close(vret.cpu(), a["vec_returns"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(vret.cpu().to(a["returns"].dtype), a["returns"], **tol(a["returns"].dtype))

@@ -58,6 +58,12 @@ def test_gae_golden(meta):
     for fn in (F.generalized_advantage_estimate, F.vec_generalized_advantage_estimate):
         adv, vt = fn(cu(G.coef(meta, a, "gamma")), cu(G.coef(meta, a, "lmbda")), cu(a["state_value"]),
                      cu(a["next_state_value"]), cu(a["reward"]), cu(done), cu(term), **G.time_kw(meta))
+        if fn is F.vec_generalized_advantage_estimate:
+            # the reference's vec variant returns promote(value dtype, dtype of a gamma*lmbda tensor) (functional.py:317-359;
+            # pinned by tests/golden/vec.npz); the values are the loop's
+            want = F._vec_gae_out_dtype(a["state_value"].dtype, G.coef(meta, a, "gamma"), G.coef(meta, a, "lmbda"))
+            assert adv.dtype == want and vt.dtype == want
+            adv, vt = adv.to(a["advantage"].dtype), vt.to(a["advantage"].dtype)
         check(adv, a["advantage"], False, a["done"])
         check(vt, a["value_target"], False, a["done"])
 

@@ -135,3 +135,26 @@ def test_td1_vs_reference_live():
             for gamma, rolling in ((0.97, None), (gam, True), (gam, False)):
                 ref = F.td1_return_estimate(gamma, nv, r, done, term, rolling, time_dim=time_dim)
                 assert torch.equal(ref, O.td1(gamma, nv, r, done, term, rolling, time_dim=time_dim))
+
+
+@pytest.mark.parametrize("meta", G.cases("vec"), ids=G.ids("vec"))
+def test_vec_fixture_loop_outputs_bit_exact(meta):
+    """tools/gen_golden_vec.py: the LOOP outputs stored beside the reference's vec outputs pin the oracle bit for bit; the
+    reference's own vec-vs-loop gap is recorded per case."""
+    a = G.arrays("vec", meta)
+    done, term = G.expand_masks(meta, a)
+    g, l = G.coef(meta, a, "gamma"), G.coef(meta, a, "lmbda")
+    adv, vt = O.gae(g, l, a["state_value"], a["next_state_value"], a["reward"], done, term, **G.time_kw(meta))
+    assert torch.equal(adv, a["advantage"]) and torch.equal(vt, a["value_target"])
+    ret = O.td_lambda(g, l, a["next_state_value"], a["reward"], done, term, None, **G.time_kw(meta))
+    wider_gamma_only = (meta["dtype"] == "f32" and meta["gamma"].get("form") == "full_f64" and meta["lmbda"]["kind"] == "float")
+    if wider_gamma_only:
+        # Documented divergence (DESIGN.md section 7): float32 values with a float64 gamma TENSOR and a scalar lmbda.  The
+        # reference keeps lmbda in the value dtype (full_like) and so forms (1 - lmbda) * v' in float32 inside an otherwise
+        # float64 recurrence (functional.py:855-857, 874-876); oracle and kernels compute every step in the promoted dtype.
+        # One float32 rounding of one product per step: pinned at 5e-7, not bit for bit.
+        torch.testing.assert_close(ret, a["returns"], rtol=5e-7, atol=5e-7)
+    else:
+        assert torch.equal(ret, a["returns"])
+    for gap in meta["reference_vec_minus_loop_max_abs"].values():
+        assert gap < 1e-4   # the reference's own tolerance between its two variants

@@ -51,7 +51,7 @@ def gae_op(state_value: Tensor, next_state_value: Tensor, reward: Tensor, done: 
 
 @gae_op.register_fake
 def _(state_value, next_state_value, reward, done, terminated, gamma, lmbda, gamma_t, lmbda_t, time_dim, vec):
-    dt = state_value.dtype if vec else next_state_value.dtype
+    dt = F._vec_gae_out_dtype(state_value.dtype, _coef(gamma, gamma_t), _coef(lmbda, lmbda_t)) if vec else next_state_value.dtype
     return (torch.empty(next_state_value.shape, dtype=dt, device=next_state_value.device),
             torch.empty(next_state_value.shape, dtype=dt, device=next_state_value.device))
 

@@ -943,12 +943,24 @@ def vec_generalized_advantage_estimate(
     if out is not None:
         return out
     call = _prepare_gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, time_dim)
-    call.out_dtype = state_value.dtype  # functional.py:314
+    call.out_dtype = _vec_gae_out_dtype(state_value.dtype, gamma, lmbda)
     if _needs_grad(state_value, next_state_value, reward, gamma, lmbda):
         return _GaeFunction.apply(state_value, next_state_value, reward, _coef_leaf(gamma, call.shape, time_dim),
                                   _coef_leaf(lmbda, call.shape, time_dim), call, None, (gamma, lmbda, time_dim))
     adv, vt, _ = _launch_gae(call)
     return adv, vt
+
+
+def _vec_gae_out_dtype(vdtype: torch.dtype, gamma, lmbda) -> torch.dtype:
+    """Output dtype of the reference's vec GAE (functional.py:314-370): scalar-like ``gamma * lmbda`` goes through
+    ``_fast_vec_gae`` and keeps the value dtype; a ``gamma * lmbda`` tensor of more than one element multiplies into the
+    advantage (``_custom_conv1d``), which then has ``promote(value dtype, that tensor's dtype)`` -- found with the vec
+    fixtures of tools/gen_golden_vec.py (float32 values, float64 gamma tensor: the loop returns float32, vec float64)."""
+    full = any(isinstance(c, torch.Tensor) and c.numel() > 1 for c in (gamma, lmbda))
+    if not full:
+        return vdtype
+    cdt = torch.result_type(gamma, lmbda)
+    return torch.promote_types(vdtype, cdt) if cdt.is_floating_point else vdtype
 
 
 def gae_with_stats(gamma, lmbda, state_value, next_state_value, reward, done, terminated=None, *, time_dim=-2,
