@@ -186,6 +186,6 @@ def test_gae_module_shifted_reads_the_single_call_buffer_in_place(monkeypatch, a
     kw = dict(obs=seq[:, :-1], next_obs=seq[:, 1:], next_reward=reward, next_done=done, next_terminated=done)
     a1, t1 = GAE(gamma=0.98, lmbda=0.94, value_network=net, average_gae=average_gae)(**kw)
     a2, t2 = GAE(gamma=0.98, lmbda=0.94, value_network=net, average_gae=average_gae, shifted=True)(**kw)
-    assert seen == [False, True]
+    assert seen in ([False, True], [True])   # the dense call may take the one-hop host path, which never asks
     torch.testing.assert_close(a1, a2, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(t1, t2, rtol=1e-5, atol=1e-5)

@@ -214,7 +214,10 @@ PyObject *py_set_workspace(PyObject *, PyObject *args) {
 
 PyObject *py_gae(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
     if (!ready(nargs, 10, "gae")) return nullptr;
-    if (!PyFloat_CheckExact(a[0]) || !PyFloat_CheckExact(a[1])) Py_RETURN_NONE;
+    // coefficients: two python floats (rounded here), or (gamma, lmbda*gamma, coef dtype code) already rounded by python
+    // (functional.scalar_gae_coef: what the modules pass for their 0-dim buffers) with None in lmbda's place
+    const bool pre = PyTuple_CheckExact(a[0]) && a[1] == Py_None;
+    if (!pre && (!PyFloat_CheckExact(a[0]) || !PyFloat_CheckExact(a[1]))) Py_RETURN_NONE;
     for (int k = 2; k <= 5; ++k) DECLINE_UNLESS_TENSOR(a[k]);
     const bool has_term = a[6] != Py_None;
     if (has_term) DECLINE_UNLESS_TENSOR(a[6]);
@@ -230,11 +233,17 @@ PyObject *py_gae(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
     if (PyErr_Occurred()) return nullptr;
 
     // gamma * int32_mask and (lmbda * gamma) * int32_mask: both take the default dtype (functional.py:172-174)
-    const auto ddt = c10::get_default_dtype_as_scalartype();
     double g_val, lg_val;
-    if (!round_to(PyFloat_AS_DOUBLE(a[0]), ddt, g_val) || !round_to(PyFloat_AS_DOUBLE(a[1]) * PyFloat_AS_DOUBLE(a[0]), ddt, lg_val))
-        Py_RETURN_NONE;
-    const int cdt = ddt == at::kFloat ? TRL_F32 : TRL_F64;
+    int cdt;
+    if (pre) {
+        if (!PyArg_ParseTuple(a[0], "ddi", &g_val, &lg_val, &cdt)) return nullptr;
+        if (cdt != TRL_F32 && cdt != TRL_F64) Py_RETURN_NONE;
+    } else {
+        const auto ddt = c10::get_default_dtype_as_scalartype();
+        if (!round_to(PyFloat_AS_DOUBLE(a[0]), ddt, g_val) || !round_to(PyFloat_AS_DOUBLE(a[1]) * PyFloat_AS_DOUBLE(a[0]), ddt, lg_val))
+            Py_RETURN_NONE;
+        cdt = ddt == at::kFloat ? TRL_F32 : TRL_F64;
+    }
 
     const at::Tensor *vals[3] = {&nsv, &sv, &r};
     Call c;

@@ -234,6 +234,8 @@ class ValueEstimatorBase(nn.Module, metaclass=abc.ABCMeta):
         self.dep_keys = {}
         self.shifted = shifted
         self._host_cache = {}
+        self._float_cache = {}
+        self._coef_cache = None
         for name, val in (("advantage_key", advantage_key), ("value_target_key", value_target_key), ("value_key", value_key)):
             if val is not None:
                 raise RuntimeError(
@@ -321,6 +323,34 @@ class ValueEstimatorBase(nn.Module, metaclass=abc.ABCMeta):
                 del self._host_cache[k]
             self._host_cache[key] = hit
         return hit[2]
+
+    def _host_float(self, t):
+        """``float`` of a scalar buffer's host mirror, cached per mirror and version (``float(tensor)`` costs a microsecond);
+        anything that is not a one-element tensor is returned unchanged."""
+        if not isinstance(t, Tensor) or t.numel() != 1:
+            return t
+        h = self._host(t)
+        c = self._float_cache.get(id(h))
+        if c is not None and c[0] is h and c[1] == h._version:
+            return c[2]
+        if len(self._float_cache) > 16:
+            self._float_cache.clear()
+        v = float(h)
+        self._float_cache[id(h)] = (h, h._version, v)   # holds h: its id cannot be reused while the entry lives
+        return v
+
+    def _gae_coef(self, gamma, lmbda):
+        """Pre-rounded ``(gamma, lmbda*gamma, dtype code)`` of two scalar host mirrors (functional.scalar_gae_coef), cached
+        until a buffer is replaced, modified or the default dtype changes; None for per-element coefficients."""
+        if not (isinstance(gamma, Tensor) and isinstance(lmbda, Tensor)) or gamma.device.type != "cpu" or lmbda.device.type != "cpu":
+            return None
+        c = self._coef_cache
+        ddt = torch.get_default_dtype()
+        if c is not None and c[0] is gamma and c[1] is lmbda and c[2] == (gamma._version, lmbda._version, ddt):
+            return c[3]
+        coef = F.scalar_gae_coef(gamma, lmbda)
+        self._coef_cache = (gamma, lmbda, (gamma._version, lmbda._version, ddt), coef)
+        return coef
 
     def _get_time_dim(self, time_dim: Optional[int], data) -> int:
         """explicit -> attribute -> dim named "time" -> last batch dim (advantages.py:409-423)."""
@@ -493,7 +523,15 @@ class GAE(ValueEstimatorBase):
             return data
         with torch.set_grad_enabled(self.differentiable):
             gamma, lmbda, value, next_value, reward, done, terminated, td = self._inputs(data, params, target_params, time_dim)
-            if self.average_gae:
+            fast = None
+            if self.process_group is None and (self.stats_exchange is None or self.differentiable):
+                coef = self._gae_coef(gamma, lmbda)
+                if coef is not None:   # scalar buffers, dense tensors, no autograd: one hop to the C ABI (functional._gae_fast)
+                    fast = F._gae_fast(coef, None, value, next_value, reward, done, terminated, 1e-4 if self.average_gae else None,
+                                       F.ALGO_AUTO, td)
+            if fast is not None:
+                adv, value_target = fast
+            elif self.average_gae:
                 adv, value_target = F.gae_normalized(gamma, lmbda, value, next_value, reward, done, terminated, eps=1e-4,
                                                      time_dim=td, group=self.process_group,
                                                      exchange=None if self.differentiable else self.stats_exchange)
@@ -557,6 +595,14 @@ class TDLambdaEstimator(ValueEstimatorBase):
         terminated = data.get(("next", self.tensor_keys.terminated), done)
         td = self._get_time_dim(time_dim, data)
         fn = F.vec_td_lambda_return_estimate if self.vectorized else F.td_lambda_return_estimate
+        # a one-element buffer acts exactly like its python float when it does not widen the result (functional._td_coef; the
+        # vec variant's output dtype is promoted by coefficient TENSORS): floats take the one-hop host path
+        if isinstance(gamma, Tensor) and gamma.numel() == 1 and (
+                not self.vectorized or torch.promote_types(next_value.dtype, gamma.dtype) == next_value.dtype):
+            gamma = self._host_float(gamma)
+        if isinstance(lmbda, Tensor) and lmbda.numel() == 1 and (
+                not self.vectorized or torch.promote_types(next_value.dtype, lmbda.dtype) == next_value.dtype):
+            lmbda = self._host_float(lmbda)
         return fn(gamma, lmbda, next_value, reward, done=done, terminated=terminated, time_dim=td)
 
 
@@ -676,9 +722,14 @@ class VTrace(ValueEstimatorBase):
             done = data.get(("next", self.tensor_keys.done))
             terminated = data.get(("next", self.tensor_keys.terminated))  # no default here (:1811)
             td = self._get_time_dim(time_dim, data)
+            rho_thresh, c_thresh = self._host(self.rho_thresh), self._host(self.c_thresh)
+            ddt = torch.get_default_dtype()
+            # default-dtype scalar buffers act exactly like their python floats (functional._scalar_mask_coef / _thresh round
+            # python numbers to the default dtype, which these already have): floats take the one-hop host path
+            if all(isinstance(t, Tensor) and t.numel() == 1 and t.dtype == ddt for t in (gamma, rho_thresh, c_thresh)):
+                gamma, rho_thresh, c_thresh = self._host_float(gamma), self._host_float(rho_thresh), self._host_float(c_thresh)
             adv, value_target = F.vtrace_advantage_estimate(gamma, log_pi, log_mu, value, next_value, reward, done, terminated,
-                                                            rho_thresh=self._host(self.rho_thresh),
-                                                            c_thresh=self._host(self.c_thresh), time_dim=td)
+                                                            rho_thresh=rho_thresh, c_thresh=c_thresh, time_dim=td)
             if self.average_adv:
                 adv = F.standardize(adv, 1e-5)
         return self._finish(data, dispatch_mode, adv, value_target)

@@ -731,14 +731,23 @@ _T32, _T64, _TBOOL = torch.float32, torch.float64, torch.bool
 _HOST = None   # the _trl_host module once _host_module() has initialised it
 
 
-def _fast_coef(gamma: float, lmbda: float):
-    """``(gamma, lmbda*gamma)`` as the reference's products with an int32 mask round them, and the coefficient dtype code."""
+def scalar_gae_coef(gamma, lmbda):
+    """``(gamma, lmbda*gamma, coefficient dtype code)`` as the reference's products with an int32 mask round them
+    (functional.py:172-174), for scalar-like ``gamma`` / ``lmbda`` -- python numbers, 0-dim or 1-element HOST tensors (the
+    modules' buffers: two float32 buffers multiply in float32, two python floats in double) -- exactly what
+    :func:`_prepare_gae` computes; None for per-element coefficients.  The tuple can stand in for ``gamma`` (with
+    ``lmbda=None``) in :func:`_gae_fast`."""
+    if _is_full(gamma) or _is_full(lmbda):
+        return None
     g_val, g_dt = _scalar_mask_coef(gamma)
     lg_val, lg_dt = _scalar_mask_coef(lmbda * gamma)
     cdt = torch.promote_types(g_dt, lg_dt)
     if cdt not in _DT:
         return None
     return g_val, lg_val, _DT[cdt]
+
+
+_fast_coef = scalar_gae_coef
 
 
 def _host_workspace(dev_index: int, O: int, T: int, I: int):
@@ -805,7 +814,8 @@ def _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, termina
         if out.__class__ is int:
             _extension.check(out, _extension.get_lib())
         return out
-    if type(gamma) is not float or type(lmbda) is not float:
+    pre = gamma if (gamma.__class__ is tuple and lmbda is None) else None
+    if pre is None and (type(gamma) is not float or type(lmbda) is not float):
         return None
     if terminated is None:
         terminated = done
@@ -838,7 +848,7 @@ def _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, termina
     if n == 0:
         return None
     key = (gamma, lmbda, torch.get_default_dtype())
-    coef = _FAST_COEF.get(key)
+    coef = pre if pre is not None else _FAST_COEF.get(key)
     if coef is None:
         g_val, g_dt = _scalar_mask_coef(gamma)
         lg_val, lg_dt = _scalar_mask_coef(lmbda * gamma)
