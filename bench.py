@@ -315,7 +315,7 @@ def main():
         dt = float(tmax.item())
 
     # the public entry point (host canonicalisation + allocation + the same launch), per call
-    entry_point_ms = None
+    entry_point_ms = module_entry_ms = None
     if not dist:
         for _ in range(50):
             F.gae_normalized(GAMMA, LMBDA, v, nv, r, done, term, eps=EPS)
@@ -325,6 +325,19 @@ def main():
             F.gae_normalized(GAMMA, LMBDA, v, nv, r, done, term, eps=EPS)
         torch.cuda.synchronize()
         entry_point_ms = (time.perf_counter() - t1) / 300 * 1e3
+        # and the module the reference's PPO recipes call: GAE(average_gae=True).forward on a tensordict-like batch
+        from torchrl_amd.objectives.value import GAE, RolloutData
+        mod = GAE(gamma=GAMMA, lmbda=LMBDA, value_network=None, average_gae=True, device=dev)
+        batch = RolloutData({"state_value": v, "next": {"state_value": nv, "reward": r, "done": done, "terminated": term}},
+                            batch_size=(O_ENVS, T_STEPS))
+        for _ in range(50):
+            mod(batch)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(300):
+            mod(batch)
+        torch.cuda.synchronize()
+        module_entry_ms = (time.perf_counter() - t1) / 300 * 1e3
 
     if rank == 0:
         n_trans = O_ENVS * T_STEPS
@@ -359,6 +372,7 @@ def main():
         if entry_point_ms is not None:
             out["entry_point_ms"] = entry_point_ms
             out["entry_point_host"] = "cxx" if F.host_fast_path() else "python"
+            out["module_entry_ms"] = module_entry_ms
         if routes:
             out["config"]["route_ms_per_step"] = routes
         if os.environ.get("TRL_BENCH_REHEARSAL"):
