@@ -130,3 +130,54 @@ def test_random_case_against_oracle(seed):
             vtol = dict(rtol=2e-5, atol=2e-5)   # device expf vs the host's: an ulp or two on every ratio
         torch.testing.assert_close(a.cpu().to(ea.dtype), ea, msg=lambda m: f"{info}: {m}", **vtol)
         torch.testing.assert_close(vs.cpu().to(ea.dtype), evs, msg=lambda m: f"{info}: {m}", **vtol)
+
+
+N_BWD = 240
+
+
+@pytest.mark.parametrize("seed", range(N_BWD))
+def test_random_backward_adjoint_identity(seed):
+    """Backward kernels on random shapes / time dims / coefficient forms / masks: every estimator is LINEAR in its value-like
+    inputs (reward, state_value, next_state_value) for fixed masks, coefficients and log-probabilities, so for any direction u
+    and any output cotangent g:  <g, F(u)> == <F^T g, u>.  F(u) is the forward path (pinned against the oracle above), F^T g
+    what autograd returns through the backward entry points (trl_*_bwd)."""
+    c = _case(10_000 + seed)
+    fn = ["gae", "vec_gae", "td_lambda", "td1", "vtrace"][seed % 5]
+    shape, dt, kw = c["shape"], c["dtype"], {"time_dim": c["time_dim"]}
+    gen = torch.Generator().manual_seed(5000 + seed)
+    mk = lambda: torch.randn(shape, generator=gen, dtype=torch.float64).to(dt).to(DEV)
+    done, term = _masks(c, gen)
+    done, term = done.to(DEV), term.to(DEV)
+    gamma = _coef(c["gform"], 0.97, shape, dt, gen)
+    lmbda = _coef(c["lform"], 0.93, shape, dt, gen)
+    gamma = gamma.to(DEV) if isinstance(gamma, torch.Tensor) else gamma
+    lmbda = lmbda.to(DEV) if isinstance(lmbda, torch.Tensor) else lmbda
+    lp = torch.rand(shape, generator=gen, dtype=torch.float64).clamp_min(1e-3).log().to(dt).to(DEV)
+    lm = torch.rand(shape, generator=gen, dtype=torch.float64).clamp_min(1e-3).log().to(dt).to(DEV)
+
+    def forward(r, v, nv):
+        if fn == "gae":
+            return F.generalized_advantage_estimate(gamma, lmbda, v, nv, r, done, term, **kw)
+        if fn == "vec_gae":
+            return F.vec_generalized_advantage_estimate(gamma, lmbda, v, nv, r, done, term, **kw)
+        if fn == "td_lambda":
+            return (F.td_lambda_return_estimate(gamma, lmbda, nv, r, done, term, **kw),)
+        if fn == "td1":
+            return (F.td1_return_estimate(gamma, nv, r, done, term, **kw),)
+        return F.vtrace_advantage_estimate(gamma, lp, lm, v, nv, r, done, term, 1.0, 0.9, **kw)
+
+    x = [mk().requires_grad_(True) for _ in range(3)]          # r, v, nv: the point does not matter for a linear map
+    outs = forward(*x)
+    gs = [torch.randn(o.shape, generator=gen, dtype=torch.float64).to(o.dtype).to(DEV) for o in outs]
+    used = [t for t in x if fn in ("gae", "vec_gae", "vtrace") or t is not x[1]]   # TD returns do not read state_value
+    grads = torch.autograd.grad(outs, used, grad_outputs=gs)
+    assert F.last_bwd_kernel() is not None
+    u = [mk() for _ in range(3)]
+    with torch.no_grad():
+        fu = forward(*u)
+    lhs = sum((g.double() * o.double()).sum() for g, o in zip(gs, fu))
+    uu = [t for t, xx in zip(u, x) if any(xx is k for k in used)]
+    rhs = sum((d.double() * t.double()).sum() for d, t in zip(grads, uu))
+    scale = sum((g.double().abs() * o.double().abs()).sum() for g, o in zip(gs, fu)) + 1.0
+    rel = (lhs - rhs).abs() / scale
+    assert rel < (2e-5 if dt == torch.float32 else 1e-12), f"{fn} {c}: <g,F(u)>={lhs.item()} <F^T g,u>={rhs.item()} rel={rel.item()} [{F.last_bwd_kernel()}]"
