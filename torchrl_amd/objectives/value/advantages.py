@@ -43,14 +43,30 @@ except Exception:  # pragma: no cover - tensordict is absent in the build image
     _TensorDictBase = None
 
 
+_UNRAVELLED = {}   # nested keys are a handful of constants per estimator: flattening them is memoised
+
+
 def _unravel_key(key: NestedKey) -> NestedKey:
-    if isinstance(key, str):
+    if key.__class__ is str:
         return key
+    try:
+        hit = _UNRAVELLED.get(key)
+    except TypeError:   # unhashable (a list): flatten without the table
+        hit = None
+        key = tuple(key)
+    if hit is not None:
+        return hit
     out = []
     for k in key:
         k = _unravel_key(k)
         out.extend(k if isinstance(k, tuple) else (k,))
-    return out[0] if len(out) == 1 else tuple(out)
+    res = out[0] if len(out) == 1 else tuple(out)
+    try:
+        if len(_UNRAVELLED) < 4096:
+            _UNRAVELLED[key] = res
+    except TypeError:
+        pass
+    return res
 
 
 class RolloutData:
