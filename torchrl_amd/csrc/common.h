@@ -33,12 +33,18 @@ __device__ __forceinline__ double dpp_mov(double x) {
     const int lo = dpp_mov<CTRL>((int)(b & 0xffffffffLL)), hi = dpp_mov<CTRL>((int)(b >> 32));
     return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
+// value of a FIXED lane as a wave-uniform scalar (v_readlane_b32: no LDS crossbar, unlike __shfl / ds_bpermute)
+__device__ __forceinline__ int read_lane(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
+__device__ __forceinline__ float read_lane(float x, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
 __device__ __forceinline__ double readlane_d(double x, int lane) {
     const long long b = __builtin_bit_cast(long long, x);
     const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
     const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
+__device__ __forceinline__ double read_lane(double x, int lane) { return readlane_d(x, lane); }
 
 // ---- wave / block reductions (fixed order => deterministic) -------------------------------
 // Sum over the 64 lanes; the result is wave-uniform.  Butterfly inside each 16-lane row with

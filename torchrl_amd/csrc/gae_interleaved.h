@@ -32,6 +32,9 @@ struct GaePreparedOp {  // what scan_chunk needs of an estimator whose per-step 
 // accesses, 64 VGPRs, 6 - 8 blocks per CU, with or without the prefetch) was measured too: 11.2 - 13.5 us at C3, dropped.
 // PMC at C3: 47 % of the LDS-array cycles are bank conflicts (the row gather walks LDS with a lane stride of V*I = 20 words:
 // 8 of 32 banks), but the LDS array is busy for only 1.85 us per CU of the 9.6 -- latency, not LDS throughput, bounds it.
+// Where the 9.6 us go (variants built with the parts removed): streaming alone (loads, delta, stores; no LDS, no scan) 7.4 us;
+// plus both LDS turns 7.8; plus the scan 9.6 -- of which 0.55 us is the scan's cross-wave stage (LDS + barrier: rows of 25
+// lanes straddle waves) and the rest VALU issue of the DPP steps (about 150 instructions per wave and chunk).
 #ifndef GIL_WAVES
 #define GIL_WAVES 4
 #endif

@@ -676,13 +676,23 @@ __device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int
     TRL_DPP_STEP(8)
 #undef TRL_DPP_STEP
     if (scan_lanes > 16) {
-        // rows 0 and 2 absorb the totals of rows 1 and 3, then rows 0 and 1 absorb rows 2..3
+        // rows 0 and 2 absorb the totals of rows 1 and 3 (lanes 16 and 48), then rows 0 and 1 absorb rows 2..3 (lane 32).
+        // The sources are three fixed lanes: v_readlane + select instead of ds_bpermute shuffles (same values, same
+        // composition order; ~2 x 120 cycles less latency per chunk on the chain scan -> carry -> replay).
         const int row = lane >> 4;
+#ifdef TRL_SCAN_SHFL  // development switch: the shuffle form
         Aff<TC> p = Aff<TC>{__shfl(S.a, (row + 1) << 4, kWave), __shfl(S.b, (row + 1) << 4, kWave),
                             __shfl(S.h, (row + 1) << 4, kWave)};
         if ((row & 1) == 0) S = compose(S, p);
         p = Aff<TC>{__shfl(S.a, 32, kWave), __shfl(S.b, 32, kWave), __shfl(S.h, 32, kWave)};
         if (row < 2) S = compose(S, p);
+#else
+        const Aff<TC> p16{read_lane(S.a, 16), read_lane(S.b, 16), read_lane(S.h, 16)};
+        const Aff<TC> p48{read_lane(S.a, 48), read_lane(S.b, 48), read_lane(S.h, 48)};
+        if ((row & 1) == 0) S = compose(S, row == 0 ? p16 : p48);
+        const Aff<TC> p32{read_lane(S.a, 32), read_lane(S.b, 32), read_lane(S.h, 32)};
+        if (row < 2) S = compose(S, p32);
+#endif
     }
     // exclusive: everything after this lane, within the wave (whole-wave shift by one lane)
     Aff<TC> E{dpp_mov<0x130>(S.a), dpp_mov<0x130>(S.b), dpp_mov<0x130>(S.h)};
