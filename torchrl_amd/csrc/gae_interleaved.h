@@ -29,7 +29,8 @@ struct GaePreparedOp {  // what scan_chunk needs of an estimator whose per-step 
 // 4 blocks of 4 waves per CU and a grid of exactly that many blocks: with the next chunk's loads in flight a lane holds two
 // sets of raw inputs, which spills at 5+ blocks per CU (measured 16 us at C3), and a grid above the resident set only queues
 // blocks behind the first round (measured: 5/CU 13.9 us, 8/CU 11.1 us, 4/CU 9.8 us).  Two elements per lane (8-byte
-// accesses, 64 VGPRs, 6 - 8 blocks per CU, with or without the prefetch) was measured too: 11.2 - 13.5 us at C3, dropped.
+// accesses, 64 VGPRs, 6 - 8 blocks per CU, with or without the prefetch) was measured too: 11.2 - 13.5 us at C3, dropped;
+// so was eight per lane (half the scans per element, one chunk per block): 11.2 us without, 18 us with the prefetch (spills).
 // PMC at C3: 47 % of the LDS-array cycles are bank conflicts (the row gather walks LDS with a lane stride of V*I = 20 words:
 // 8 of 32 banks), but the LDS array is busy for only 1.85 us per CU of the 9.6 -- latency, not LDS throughput, bounds it.
 // Where the 9.6 us go (variants built with the parts removed): streaming alone (loads, delta, stores; no LDS, no scan) 7.4 us;
