@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define TRL_ABI_VERSION 5
+#define TRL_ABI_VERSION 6
 
 enum { TRL_F32 = 0, TRL_F64 = 1 };
 
@@ -256,6 +256,18 @@ int trl_td1_bwd(void *stream, int val_dtype, int coef_dtype, const void *grad_re
                 int64_t O, int64_t T, int64_t I,
                 void *d_reward, void *d_next_state_value,
                 void *workspace, size_t workspace_bytes, int algo);
+/* trl_td_fixed_bwd: backward of the rolling_gamma=False forms (td_lambda_return_estimate, functional.py:877-887; td1_return_estimate,
+ * :550-561; `td1` selects which).  R_k reruns the tail T-1..k with the coefficients of step k held fixed, so the gradients are column
+ * sums of the O(T^2) matrix of tail products (d_reward, d_next_state_value: one wave per (o, i) row, deterministic wave reductions)
+ * and forward-mode derivatives along each tail (d_gamma_t, d_lmbda_t: per element, coef_dtype-promoted compute dtype; they need
+ * `reward` and `next_state_value`, which may be NULL otherwise).  Outputs that are NULL are not computed.  O(T^2) work per row, as
+ * the forward call; no workspace, one family. */
+int trl_td_fixed_bwd(void *stream, int val_dtype, int coef_dtype, int td1, const void *grad_returns,
+                     const void *reward, const void *next_state_value,
+                     const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                     const void *gamma_t, const void *lmbda_t, double gamma, double lmbda,
+                     int64_t O, int64_t T, int64_t I,
+                     void *d_reward, void *d_next_state_value, void *d_gamma_t, void *d_lmbda_t);
 /* trl_vtrace_bwd: grad_advantage / grad_vs and `vs` (the forward call's second output, saved) have dtype
  *   promote(val_dtype, coef_dtype); gradients w.r.t. log_pi, log_mu (= -d_log_pi), state_value, next_state_value, reward
  *   have val_dtype; d_gamma_t (optional, per element) has the promoted dtype.  The clipped branches of min(rho, thresh)

@@ -14,6 +14,8 @@ with open(os.path.join(GOLDEN, "manifest_next.json")) as _f:  # tools/gen_golden
     MANIFEST.update({k: v for k, v in json.load(_f).items() if isinstance(v, list)})
 with open(os.path.join(GOLDEN, "manifest_vec.json")) as _f:   # tools/gen_golden_vec.py: the reference's vec variants beside its loops
     MANIFEST.update({k: v for k, v in json.load(_f).items() if isinstance(v, list)})
+with open(os.path.join(GOLDEN, "manifest_grads_nr.json")) as _f:   # tools/gen_golden_grads_nr.py: gradients of rolling_gamma=False
+    MANIFEST.update({k: v for k, v in json.load(_f).items() if isinstance(v, list)})
 _npz = {}
 
 

@@ -153,3 +153,57 @@ def test_gae_backward_adjoint_identity_full_size():
     assert F.last_bwd_kernel() == "gae_bwd_scan"
     rhs = (dr * r).sum() + (dv * v).sum() + (dnv * nv).sum()
     torch.testing.assert_close(lhs.detach(), rhs.detach(), rtol=1e-10, atol=1e-6)
+
+
+# ---- rolling_gamma=False (trl_td_fixed_bwd): tests/golden/grads_nr.npz, tools/gen_golden_grads_nr.py ----------------------------
+@pytest.mark.parametrize("meta", G.cases("grads_nr", "td_lambda"), ids=G.ids("grads_nr", "td_lambda"))
+def test_td_lambda_nonrolling_grads_golden(meta):
+    a = G.arrays("grads_nr", meta)
+    r, nv = leaf(a["reward"]), leaf(a["next_state_value"])
+    g, gl = coef(meta, a, "gamma")
+    l, ll = coef(meta, a, "lmbda")
+    ret = F.td_lambda_return_estimate(g, l, nv, r, a["done"].to(DEV), a["terminated"].to(DEV), False, **kw(meta))
+    torch.testing.assert_close(ret.detach().cpu(), a["returns"], **tol(a["returns"].dtype))
+    ins = [r, nv] + [x for x in (gl, ll) if x is not None]
+    names = ["reward", "next_state_value"] + [n for n, x in (("gamma", gl), ("lmbda", ll)) if x is not None]
+    compare(torch.autograd.grad((ret * a["w_returns"].to(DEV)).sum(), ins), a, names)
+    assert "fixed_bwd" in F.last_bwd_kernel()
+
+
+@pytest.mark.parametrize("meta", G.cases("grads_nr", "td1"), ids=G.ids("grads_nr", "td1"))
+def test_td1_nonrolling_grads_golden(meta):
+    a = G.arrays("grads_nr", meta)
+    r, nv = leaf(a["reward"]), leaf(a["next_state_value"])
+    g, gl = coef(meta, a, "gamma")
+    ret = F.td1_return_estimate(g, nv, r, a["done"].to(DEV), a["terminated"].to(DEV), False, **kw(meta))
+    torch.testing.assert_close(ret.detach().cpu(), a["returns"], **tol(a["returns"].dtype))
+    compare(torch.autograd.grad((ret * a["w_returns"].to(DEV)).sum(), [r, nv, gl]), a, ["reward", "next_state_value", "gamma"])
+    assert "fixed_bwd" in F.last_bwd_kernel()
+
+
+def test_nonrolling_backward_value_gradients_only_and_expanded_masks():
+    """Only the value-like inputs require grad (no coefficient kernel), masks expanded over I > 1 (compact form)."""
+    g = torch.Generator().manual_seed(4)
+    shape = (3, 150, 2)
+    r, nv = (torch.randn(shape, generator=g, dtype=torch.float64).to(DEV).requires_grad_(True) for _ in range(2))
+    gam = (0.9 + 0.1 * torch.rand(shape, generator=g, dtype=torch.float64)).to(DEV)
+    term = (torch.rand(3, 150, 1, generator=g) < 0.03).to(DEV)
+    done = (term | (torch.rand(3, 150, 1, generator=g) < 0.03).to(DEV)).expand(shape)
+    term = term.expand(shape)
+    w = torch.randn(shape, generator=g, dtype=torch.float64).to(DEV)
+    ret = F.td_lambda_return_estimate(gam, 0.9, nv, r, done, term, False)
+    d_nv, d_r = torch.autograd.grad((ret * w).sum(), (nv, r))
+    # the same through torch autograd over a python restatement of functional.py:877-887
+    r2, nv2 = r.detach().clone().requires_grad_(True), nv.detach().clone().requires_grad_(True)
+    nvm = nv2 * (~term).to(nv2.dtype)
+    dn = done.to(nv2.dtype)
+    outs = []
+    for k in range(shape[1]):
+        gk = nvm[:, -1]
+        for i in reversed(range(k, shape[1])):
+            gk = gk * (1 - dn[:, i]) + nvm[:, i] * dn[:, i]
+            gk = r2[:, i] + gam[:, k] * ((1 - 0.9) * nvm[:, i] + 0.9 * gk)
+        outs.append(gk)
+    want = torch.autograd.grad((torch.stack(outs, 1) * w).sum(), (nv2, r2))
+    torch.testing.assert_close(d_nv, want[0], rtol=1e-10, atol=1e-10)
+    torch.testing.assert_close(d_r, want[1], rtol=1e-10, atol=1e-10)

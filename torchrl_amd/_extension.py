@@ -19,7 +19,7 @@ import warnings
 _LIB_NAME = "libtrl_value.so"
 # TRL_VALUE_LIB: development switch (kernel variants built beside the product library); unset in normal use
 _LIB_PATH = os.environ.get("TRL_VALUE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EXTENSION_WARNING = (
     f"Failed to load the torchrl_amd HIP library ({_LIB_PATH}). The value estimators "
@@ -64,6 +64,8 @@ _PROTOTYPES = {
                                  _i64, _i64, _i64, _vp, _vp, _vp, _sz, _int]),
     "trl_td1_bwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _int, _vp, _dbl,
                            _i64, _i64, _i64, _vp, _vp, _vp, _sz, _int]),
+    "trl_td_fixed_bwd": (_int, [_vp, _int, _int, _int, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl,
+                                _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "trl_vtrace_bwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _dbl, _dbl, _dbl, _vp, _vp,
                               _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _int]),
     "trl_normalize": (_int, [_vp, _int, _vp, _i64, _vp, _dbl, _vp]),

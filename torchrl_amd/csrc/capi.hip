@@ -266,6 +266,27 @@ extern "C" int trl_td1_bwd(void *stream, int val_dtype, int coef_dtype, const vo
                        gamma, 1.0, O, T, I, d_reward, d_next_state_value, workspace, workspace_bytes, algo);
 }
 
+extern "C" int trl_td_fixed_bwd(void *stream, int val_dtype, int coef_dtype, int td1, const void *grad_returns, const void *reward,
+                                const void *next_state_value, const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                                const void *gamma_t, const void *lmbda_t, double gamma, double lmbda, int64_t O, int64_t T, int64_t I,
+                                void *d_reward, void *d_next_state_value, void *d_gamma_t, void *d_lmbda_t) {
+    const char *fn = "trl_td_fixed_bwd";
+    if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "%s: bad dtype", fn);
+    if (int rc = check_dims(fn, O, T, I)) return rc;
+    if (!grad_returns || !done || !terminated) return fail(TRL_ERR_INVALID_ARGUMENT, "%s: null tensor pointer", fn);
+    if (!d_reward && !d_next_state_value && !d_gamma_t && !d_lmbda_t) return fail(TRL_ERR_INVALID_ARGUMENT, "%s: no output requested", fn);
+    if ((d_gamma_t || d_lmbda_t) && (!reward || !next_state_value))
+        return fail(TRL_ERR_INVALID_ARGUMENT, "%s: coefficient gradients need reward and next_state_value", fn);
+    if (td1 && d_lmbda_t) return fail(TRL_ERR_INVALID_ARGUMENT, "%s: TD(1) has no lmbda", fn);
+    TdFixedBwdArgs a{grad_returns, reward, next_state_value, done, terminated, gamma_t, td1 ? nullptr : lmbda_t, gamma, td1 ? 1.0 : lmbda,
+                     O, T, I, d_reward, d_next_state_value, d_gamma_t, d_lmbda_t, (mask_bcast && I > 1) ? 1 : 0};
+    LaunchResult res = launch_td_fixed_bwd((hipStream_t)stream, val_dtype, coef_dtype, a, td1 ? 1 : 0);
+    if (res.status != 0) return fail(res.status, "%s: launch rejected (grid too large?)", fn);
+    if (int rc = check_launch(fn)) return rc;
+    g_kernel = res.kernel;
+    return TRL_OK;
+}
+
 extern "C" int trl_vtrace_bwd(void *stream, int val_dtype, int coef_dtype, const void *grad_advantage, const void *grad_vs,
                               const void *log_pi, const void *log_mu, const void *state_value, const void *next_state_value,
                               const void *reward, const void *vs, const uint8_t *done, const uint8_t *terminated, int mask_bcast,

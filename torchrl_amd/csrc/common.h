@@ -144,6 +144,17 @@ struct TdBwdArgs {  // TD(lambda) (rolling gamma) and TD(1) (lmbda unused)
     int mask_bcast;
 };
 
+struct TdFixedBwdArgs {  // rolling_gamma=False forms of TD(lambda) / TD(1) (bwd_fixed_kernels.hip)
+    const void *g_ret, *reward, *next_value;
+    const u8 *done, *terminated;
+    const void *gamma_t, *lmbda_t;
+    double gamma, lmbda;
+    i64 O, T, I;
+    void *d_reward, *d_next_value;  // value dtype
+    void *d_gamma, *d_lmbda;        // compute dtype, per element (the gradient w.r.t. the coefficient of start k)
+    int mask_bcast;
+};
+
 struct VtraceBwdArgs {
     const void *g_adv, *g_vs;  // compute dtype (what trl_vtrace_fwd wrote)
     const void *log_pi, *log_mu, *value, *next_value, *reward;
@@ -174,6 +185,7 @@ LaunchResult launch_gae_bwd_scan(hipStream_t s, int vdt, int cdt, const GaeBwdAr
 LaunchResult launch_gae_bwd_seq(hipStream_t s, int vdt, int cdt, const GaeBwdArgs &a);
 LaunchResult launch_td_bwd_scan(hipStream_t s, int vdt, int cdt, const TdBwdArgs &a, int td1, void *lb_ws, size_t lb_bytes);
 LaunchResult launch_td_bwd_seq(hipStream_t s, int vdt, int cdt, const TdBwdArgs &a, int td1);
+LaunchResult launch_td_fixed_bwd(hipStream_t s, int vdt, int cdt, const TdFixedBwdArgs &a, int td1);
 LaunchResult launch_vtrace_bwd_scan(hipStream_t s, int vdt, int cdt, const VtraceBwdArgs &a, void *lb_ws, size_t lb_bytes);
 LaunchResult launch_vtrace_bwd_seq(hipStream_t s, int vdt, int cdt, const VtraceBwdArgs &a);
 

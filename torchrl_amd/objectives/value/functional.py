@@ -580,6 +580,25 @@ def _td_bwd(c, g_ret, td1: bool, need_nv: bool, need_r: bool):
     return d_nv, d_r
 
 
+def _td_fixed_bwd(c, g_ret, td1: bool, need_nv: bool, need_r: bool, need_gamma: bool, need_lmbda: bool):
+    """Gradients of the ``rolling_gamma=False`` forms through trl_td_fixed_bwd: ``(d_next_state_value, d_reward)`` in the value
+    dtype and the per-element ``(d_gamma, d_lmbda)`` in the compute dtype (None where not needed)."""
+    lib = _extension.get_lib()
+    dev = c.reward.device
+    gr = _grad_in(g_ret, c, c.vdt)
+    cdt = torch.promote_types(c.vdt, c.cdt)
+    new = lambda on, dt: torch.empty(c.shape, dtype=dt, device=dev) if on else None
+    d_nv, d_r, d_g, d_l = new(need_nv, c.vdt), new(need_r, c.vdt), new(need_gamma, cdt), new(need_lmbda and not td1, cdt)
+    if d_nv is None and d_r is None and d_g is None and d_l is None:
+        return None, None, None, None
+    with _on(dev):
+        rc = lib.trl_td_fixed_bwd(_stream(dev), _DT[c.vdt], _DT[c.cdt], 1 if td1 else 0, _ptr(gr), _ptr(c.reward), _ptr(c.next_value),
+                                  _ptr(c.done), _ptr(c.terminated), c.mask_bcast, _ptr(c.gamma_t), _ptr(c.lmbda_t), c.gamma, c.lmbda,
+                                  c.O, c.T, c.I, _ptr(d_r), _ptr(d_nv), _ptr(d_g), _ptr(d_l))
+    _bwd_done(rc, lib)
+    return d_nv, d_r, d_g, d_l
+
+
 class _TdLambdaFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, next_state_value, reward, gamma_e, lmbda_e, call, out_dtype, coefs):
@@ -596,13 +615,17 @@ class _TdLambdaFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_ret):
         c = ctx.call
-        if not c.rolling:
-            raise NotImplementedError("backward of td_lambda_return_estimate(rolling_gamma=False) is not implemented")
         gamma_e, lmbda_e = ctx.leaves
         want_coef = gamma_e is not None or lmbda_e is not None
         if g_ret is None:
             return (None,) * 7
         need = ctx.needs_input_grad
+        if not c.rolling:   # O(T^2) form: its own kernels, coefficient gradients included (trl_td_fixed_bwd)
+            d_nv, d_r, d_g, d_l = _td_fixed_bwd(c, g_ret, False, need[0], need[1], gamma_e is not None, lmbda_e is not None)
+            outs = tuple(None if o is None or not n else o.to(d).view(s)
+                         for o, n, d, s in zip((d_nv, d_r), need[:2], ctx.in_dtypes, ctx.in_shapes))
+            return outs + (_coef_grad(d_g, gamma_e, c) if d_g is not None else None,
+                           _coef_grad(d_l, lmbda_e, c) if d_l is not None else None, None, None, None)
         d_nv, d_r = _td_bwd(c, g_ret, False, need[0], need[1] or want_coef)
         d_gamma = d_lmbda = None
         if want_coef:
@@ -643,12 +666,15 @@ class _Td1Function(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_ret):
         c = ctx.call
-        if not c.rolling:
-            raise NotImplementedError("backward of td1_return_estimate(rolling_gamma=False) is not implemented")
         if g_ret is None:
             return (None,) * 5
         need = ctx.needs_input_grad
         want_coef = ctx.gamma_e is not None
+        if not c.rolling:   # O(T^2) form (trl_td_fixed_bwd)
+            d_nv, d_r, d_g, _ = _td_fixed_bwd(c, g_ret, True, need[0], need[1], want_coef, False)
+            outs = tuple(None if o is None or not n else o.to(d).view(s)
+                         for o, n, d, s in zip((d_nv, d_r), need[:2], ctx.in_dtypes, ctx.in_shapes))
+            return outs + (_coef_grad(d_g, ctx.gamma_e, c) if d_g is not None else None, None, None)
         d_nv, d_r = _td_bwd(c, g_ret, True, need[0], need[1] or want_coef)
         d_gamma = None
         if want_coef:
