@@ -197,6 +197,7 @@ struct VtraceBwdOp {
     // (256-thread blocks) fp32 gains more from the fourth wave per SIMD than from the prefetch, fp64 the other way round
     // (C5 fp32 135 -> 114 us, fp64 261 with vs 325 without; C4 fp32 34 -> 23 us together with V = 2, fp64 99 -> 60).
     static constexpr bool kPrefetchShort = false, kPrefetchLong = sizeof(TS_) == 8;
+    static constexpr bool kDualScan = false;  // scan_impl.h: OpDualScan
     typedef TS TO;
     static constexpr int kNumOut = 1;
     struct Raw {

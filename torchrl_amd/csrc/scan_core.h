@@ -29,6 +29,18 @@ __device__ __forceinline__ TC apply(const Aff<TC> &f, TC x) {
     const TC t = f.b + f.a * x;
     return f.h ? f.b : t;
 }
+// The same two for a chunk that holds no row end (HARD = false): no map carries a hard reset, h stays 0 and is neither
+// moved between lanes nor selected on -- a quarter of the scan's instructions (interior chunks of long rows).
+template <bool HARD, typename TC>
+__device__ __forceinline__ Aff<TC> compose_t(const Aff<TC> &f1, const Aff<TC> &f2) {
+    if constexpr (HARD) return compose(f1, f2);
+    return Aff<TC>{f1.a * f2.a, f1.b + f1.a * f2.b, 0};
+}
+template <bool HARD, typename TC>
+__device__ __forceinline__ TC apply_t(const Aff<TC> &f, TC x) {
+    if constexpr (HARD) return apply(f, x);
+    return f.b + f.a * x;
+}
 template <typename TC>
 __device__ __forceinline__ Aff<TC> shfl_down_aff(const Aff<TC> &f, int off) {
     Aff<TC> r;
@@ -619,8 +631,8 @@ struct LaneGeom {
 //   emit(xs, row_end, x_in, v_next): consumes the per-step results.
 //   carry_fn(sh, buf, Xc, Xv): called by every thread once the wave aggregates are in LDS; a kernel
 //   that learns its carry from other blocks (decoupled look-back) resolves Xc / Xv there.
-template <class Op, bool WAVE_INDEP, class Emit, class CarryFn>
-__device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int buf, int nvalid, unsigned t0, unsigned T,
+template <class Op, bool WAVE_INDEP, bool HARD, class Emit, class CarryFn>
+__device__ __forceinline__ void scan_chunk_t(const Op &op, TeamShared<Op> &sh, int buf, int nvalid, unsigned t0, unsigned T,
                                            int scan_lanes, typename Op::TC &Xc, typename Op::TS &Xv, Emit &&emit,
                                            CarryFn &&carry_fn) {
     typedef typename Op::TC TC;
@@ -634,7 +646,7 @@ __device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int
         unsigned t = t0;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            row_end[e] = (t == T - 1);
+            row_end[e] = HARD && (t == T - 1);   // HARD = false: the caller knows that the chunk holds no row end
             t = row_end[e] ? 0u : t + 1u;
         }
     }
@@ -653,7 +665,7 @@ __device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int
                 op.affine(e, el.a, el.b);
                 el.h = 0;
             }
-            agg = (e == V - 1) ? el : compose(el, agg);
+            agg = (e == V - 1) ? el : compose_t<HARD>(el, agg);
         }
     }
 
@@ -667,8 +679,8 @@ __device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int
         Aff<TC> p;                                                                 \
         p.a = dpp_mov<0x100 + OFF>(S.a);                                           \
         p.b = dpp_mov<0x100 + OFF>(S.b);                                           \
-        p.h = dpp_mov<0x100 + OFF>(S.h);                                           \
-        if (lir + OFF < 16) S = compose(S, p);                                     \
+        p.h = HARD ? dpp_mov<0x100 + OFF>(S.h) : 0;                                \
+        if (lir + OFF < 16) S = compose_t<HARD>(S, p);                             \
     }
     TRL_DPP_STEP(1)
     TRL_DPP_STEP(2)
@@ -683,19 +695,19 @@ __device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int
 #ifdef TRL_SCAN_SHFL  // development switch: the shuffle form
         Aff<TC> p = Aff<TC>{__shfl(S.a, (row + 1) << 4, kWave), __shfl(S.b, (row + 1) << 4, kWave),
                             __shfl(S.h, (row + 1) << 4, kWave)};
-        if ((row & 1) == 0) S = compose(S, p);
+        if ((row & 1) == 0) S = compose_t<HARD>(S, p);
         p = Aff<TC>{__shfl(S.a, 32, kWave), __shfl(S.b, 32, kWave), __shfl(S.h, 32, kWave)};
-        if (row < 2) S = compose(S, p);
+        if (row < 2) S = compose_t<HARD>(S, p);
 #else
-        const Aff<TC> p16{read_lane(S.a, 16), read_lane(S.b, 16), read_lane(S.h, 16)};
-        const Aff<TC> p48{read_lane(S.a, 48), read_lane(S.b, 48), read_lane(S.h, 48)};
-        if ((row & 1) == 0) S = compose(S, row == 0 ? p16 : p48);
-        const Aff<TC> p32{read_lane(S.a, 32), read_lane(S.b, 32), read_lane(S.h, 32)};
-        if (row < 2) S = compose(S, p32);
+        const Aff<TC> p16{read_lane(S.a, 16), read_lane(S.b, 16), HARD ? read_lane(S.h, 16) : 0};
+        const Aff<TC> p48{read_lane(S.a, 48), read_lane(S.b, 48), HARD ? read_lane(S.h, 48) : 0};
+        if ((row & 1) == 0) S = compose_t<HARD>(S, row == 0 ? p16 : p48);
+        const Aff<TC> p32{read_lane(S.a, 32), read_lane(S.b, 32), HARD ? read_lane(S.h, 32) : 0};
+        if (row < 2) S = compose_t<HARD>(S, p32);
 #endif
     }
     // exclusive: everything after this lane, within the wave (whole-wave shift by one lane)
-    Aff<TC> E{dpp_mov<0x130>(S.a), dpp_mov<0x130>(S.b), dpp_mov<0x130>(S.h)};
+    Aff<TC> E{dpp_mov<0x130>(S.a), dpp_mov<0x130>(S.b), HARD ? dpp_mov<0x130>(S.h) : 0};
     if (lane == kWave - 1) E = Aff<TC>{(TC)1, (TC)0, 0};
     TS v_next = Op::kNeedsNext ? dpp_mov<0x130>(op.first_value()) : (TS)0;
 
@@ -708,7 +720,7 @@ __device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int
         if (lane == 0) {
             sh.a[buf][w] = S.a;
             sh.b[buf][w] = S.b;
-            sh.h[buf][w] = S.h;
+            if (HARD) sh.h[buf][w] = S.h;
             if (Op::kNeedsNext) sh.v0[buf][w] = op.first_value();
         }
         __syncthreads();
@@ -720,8 +732,8 @@ __device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int
 #pragma unroll
         for (int k = kWaves - 1; k >= 0; --k) {
             if (k == w) { Cw = x; Cv = xv; }
-            const Aff<TC> g{sh.a[buf][k], sh.b[buf][k], sh.h[buf][k]};
-            x = apply(g, x);
+            const Aff<TC> g{sh.a[buf][k], sh.b[buf][k], HARD ? sh.h[buf][k] : 0};
+            x = apply_t<HARD>(g, x);
             if (Op::kNeedsNext) xv = sh.v0[buf][k];
         }
         Xc = x;  // x of the chunk's first element
@@ -731,7 +743,7 @@ __device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int
 
     // 4. exact per-step replay from the lane's carry-in
     TC xs[V];
-    const TC x_in = apply(E, Cw);
+    const TC x_in = apply_t<HARD>(E, Cw);
     TC xp = x_in;
 #pragma unroll
     for (int e = V - 1; e >= 0; --e) {
@@ -740,6 +752,13 @@ __device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int
         if (e < nvalid) xp = xs[e];
     }
     emit(xs, row_end, x_in, v_next);
+}
+
+template <class Op, bool WAVE_INDEP, class Emit, class CarryFn>
+__device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int buf, int nvalid, unsigned t0, unsigned T,
+                                           int scan_lanes, typename Op::TC &Xc, typename Op::TS &Xv, Emit &&emit,
+                                           CarryFn &&carry_fn) {
+    scan_chunk_t<Op, WAVE_INDEP, true>(op, sh, buf, nvalid, t0, T, scan_lanes, Xc, Xv, emit, carry_fn);
 }
 
 template <class Op, bool WAVE_INDEP, class Emit>

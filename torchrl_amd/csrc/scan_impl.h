@@ -287,7 +287,15 @@ __global__ __launch_bounds__(kTeam, IL_WAVES) void scan_interleaved_kernel(typen
 }
 
 // ---- LONG rows: one team per block walks (row, chunk) pairs from each row's end -----------------
-template <class Op, bool VEC>
+// DUAL: interior chunks (no row end inside) take the scan without the hard-reset machinery.  Chosen by the launcher for rows
+// of 4+ chunks (a second copy of the scan code costs a two-chunk row more in instruction fetch than it saves: C1 5.1 -> 7.8 us)
+// and for ops that keep their registers with two copies inlined (not V-trace backward: 116 -> 159 us at C5).
+template <class Op, class = void>
+struct OpDualScan { static constexpr bool value = true; };
+template <class Op>
+struct OpDualScan<Op, std::void_t<decltype(Op::kDualScan)>> { static constexpr bool value = Op::kDualScan; };
+
+template <class Op, bool VEC, bool DUAL>
 __global__ __launch_bounds__(kLongThreads) void scan_long_kernel(typename Op::Args args, ScanGeom geo, double *partials) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
@@ -325,10 +333,13 @@ __global__ __launch_bounds__(kLongThreads) void scan_long_kernel(typename Op::Ar
         if (!PF) load_inputs<Op, VEC>(args, flat, nvalid, cur);
         Op op;
         op.prepare(args, cur);
-        scan_chunk<Op, false>(op, sh, buf, nvalid, (unsigned)((i64)c * kChunk + lane_off), T, kWave, Xc, Xv,
-                              [&](const TC(&xs)[V], const bool(&row_end)[V], TC x_in, TS v_next) {
-                                  emit_outputs<Op, VEC>(op, args, flat, nvalid, xs, row_end, x_in, v_next, s, ss);
-                              });
+        auto emit = [&](const TC(&xs)[V], const bool(&row_end)[V], TC x_in, TS v_next) {
+            emit_outputs<Op, VEC>(op, args, flat, nvalid, xs, row_end, x_in, v_next, s, ss);
+        };
+        auto no_carry = [](TeamShared<Op> &, int, TC &, TS &) {};
+        // only a row's last chunk holds its end: every other chunk scans without the hard-reset machinery (scan_core.h)
+        if (!DUAL || c == nchunks - 1) scan_chunk_t<Op, false, true>(op, sh, buf, nvalid, (unsigned)((i64)c * kChunk + lane_off), T, kWave, Xc, Xv, emit, no_carry);
+        else scan_chunk_t<Op, false, false>(op, sh, buf, nvalid, (unsigned)((i64)c * kChunk + lane_off), T, kWave, Xc, Xv, emit, no_carry);
         buf ^= 1;
         if (PF) cur = nxt;
         row = nrow;
@@ -641,8 +652,17 @@ LaunchResult launch_scan(hipStream_t s, const typename Op::Args &a, const Plan &
         if (p.vec) hipLaunchKernelGGL((scan_lookback_kernel<Op, true>), grid, dim3(kLbTeams * kTeam), 0, s, a, geo, hdr, rec);
         else hipLaunchKernelGGL((scan_lookback_kernel<Op, false>), grid, dim3(kLbTeams * kTeam), 0, s, a, geo, hdr, rec);
     } else if (p.long_rows) {
-        if (p.vec) hipLaunchKernelGGL((scan_long_kernel<Op, true>), grid, dim3(kLongThreads), 0, s, a, geo, partials);
-        else hipLaunchKernelGGL((scan_long_kernel<Op, false>), grid, dim3(kLongThreads), 0, s, a, geo, partials);
+        const bool dual = OpDualScan<Op>::value && T >= 4 * (i64)kLongThreads * Op::V;
+        if constexpr (OpDualScan<Op>::value) {
+            if (dual) {
+                if (p.vec) hipLaunchKernelGGL((scan_long_kernel<Op, true, true>), grid, dim3(kLongThreads), 0, s, a, geo, partials);
+                else hipLaunchKernelGGL((scan_long_kernel<Op, false, true>), grid, dim3(kLongThreads), 0, s, a, geo, partials);
+            }
+        }
+        if (!dual) {
+            if (p.vec) hipLaunchKernelGGL((scan_long_kernel<Op, true, false>), grid, dim3(kLongThreads), 0, s, a, geo, partials);
+            else hipLaunchKernelGGL((scan_long_kernel<Op, false, false>), grid, dim3(kLongThreads), 0, s, a, geo, partials);
+        }
     } else {
 #define TRL_LAUNCH(VEC, WI) hipLaunchKernelGGL((scan_short_kernel<Op, VEC, WI>), grid, dim3(kShortThreads), 0, s, a, geo, partials)
         if (p.wave_indep) { if (p.vec) TRL_LAUNCH(true, true); else TRL_LAUNCH(false, true); }
