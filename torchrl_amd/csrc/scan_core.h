@@ -631,13 +631,21 @@ struct LaneGeom {
 //   emit(xs, row_end, x_in, v_next): consumes the per-step results.
 //   carry_fn(sh, buf, Xc, Xv): called by every thread once the wave aggregates are in LDS; a kernel
 //   that learns its carry from other blocks (decoupled look-back) resolves Xc / Xv there.
-template <class Op, bool WAVE_INDEP, bool HARD, class Emit, class CarryFn>
+// MODE of scan_chunk_t:
+//   kScanGeneral   rows may end anywhere: maps carry the hard-reset flag h
+//   kScanNoRowEnd  the caller knows the chunk holds no row end (interior chunk of a long row): no h, no row-end logic
+// (A third form -- rows as aligned power-of-two lane groups, steps bounded by the group instead of guarded by h -- was
+// measured in the fused kernel at C4: no gain, 7.87 vs 7.77 us per step; dropped.)
+constexpr int kScanGeneral = 0, kScanNoRowEnd = 1;
+
+template <class Op, bool WAVE_INDEP, int MODE, class Emit, class CarryFn>
 __device__ __forceinline__ void scan_chunk_t(const Op &op, TeamShared<Op> &sh, int buf, int nvalid, unsigned t0, unsigned T,
                                            int scan_lanes, typename Op::TC &Xc, typename Op::TS &Xv, Emit &&emit,
                                            CarryFn &&carry_fn) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
     constexpr int V = Op::V;
+    constexpr bool HARD = MODE == kScanGeneral;
     const int lane = threadIdx.x & (kWave - 1), w = (threadIdx.x / kWave) & (kWaves - 1);
 
     // time index of each element -> row-end flags
@@ -646,7 +654,7 @@ __device__ __forceinline__ void scan_chunk_t(const Op &op, TeamShared<Op> &sh, i
         unsigned t = t0;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
-            row_end[e] = HARD && (t == T - 1);   // HARD = false: the caller knows that the chunk holds no row end
+            row_end[e] = MODE != kScanNoRowEnd && (t == T - 1);
             t = row_end[e] ? 0u : t + 1u;
         }
     }
@@ -758,7 +766,7 @@ template <class Op, bool WAVE_INDEP, class Emit, class CarryFn>
 __device__ __forceinline__ void scan_chunk(const Op &op, TeamShared<Op> &sh, int buf, int nvalid, unsigned t0, unsigned T,
                                            int scan_lanes, typename Op::TC &Xc, typename Op::TS &Xv, Emit &&emit,
                                            CarryFn &&carry_fn) {
-    scan_chunk_t<Op, WAVE_INDEP, true>(op, sh, buf, nvalid, t0, T, scan_lanes, Xc, Xv, emit, carry_fn);
+    scan_chunk_t<Op, WAVE_INDEP, kScanGeneral>(op, sh, buf, nvalid, t0, T, scan_lanes, Xc, Xv, emit, carry_fn);
 }
 
 template <class Op, bool WAVE_INDEP, class Emit>

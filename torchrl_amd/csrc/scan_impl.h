@@ -338,8 +338,8 @@ __global__ __launch_bounds__(kLongThreads) void scan_long_kernel(typename Op::Ar
         };
         auto no_carry = [](TeamShared<Op> &, int, TC &, TS &) {};
         // only a row's last chunk holds its end: every other chunk scans without the hard-reset machinery (scan_core.h)
-        if (!DUAL || c == nchunks - 1) scan_chunk_t<Op, false, true>(op, sh, buf, nvalid, (unsigned)((i64)c * kChunk + lane_off), T, kWave, Xc, Xv, emit, no_carry);
-        else scan_chunk_t<Op, false, false>(op, sh, buf, nvalid, (unsigned)((i64)c * kChunk + lane_off), T, kWave, Xc, Xv, emit, no_carry);
+        if (!DUAL || c == nchunks - 1) scan_chunk_t<Op, false, kScanGeneral>(op, sh, buf, nvalid, (unsigned)((i64)c * kChunk + lane_off), T, kWave, Xc, Xv, emit, no_carry);
+        else scan_chunk_t<Op, false, kScanNoRowEnd>(op, sh, buf, nvalid, (unsigned)((i64)c * kChunk + lane_off), T, kWave, Xc, Xv, emit, no_carry);
         buf ^= 1;
         if (PF) cur = nxt;
         row = nrow;
