@@ -5,6 +5,7 @@ KiB; FETCH_SIZE counts wide coalesced reads at half their bytes on gfx950 -> x2.
 import csv
 import glob
 import json
+import os
 import sys
 
 fetch_dir, write_dir, out = sys.argv[1:4]
@@ -13,7 +14,8 @@ needle = sys.argv[4] if len(sys.argv) > 4 else "gae_fused_kernel"
 
 def collect(d, counter):
     vals = []
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    for f in ([max(files, key=os.path.getmtime)] if files else []):   # newest run only: gpurun_out keeps earlier ones
         for row in csv.DictReader(open(f)):
             if needle in row["Kernel_Name"] and row["Counter_Name"] == counter:
                 vals.append(float(row["Counter_Value"]))

@@ -9,7 +9,8 @@ import sys
 
 tag, rnd = sys.argv[1], sys.argv[2]
 pre = f"profiles/r{rnd}_{tag}_bench"
-f = glob.glob(f"gpurun_out/prof_{tag}/**/*_kernel_stats.csv", recursive=True)[0]
+import os
+f = max(glob.glob(f"gpurun_out/prof_{tag}/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)  # newest: gpurun_out keeps earlier runs
 rows = list(csv.DictReader(open(f)))
 with open(pre + "_kernel_stats.csv", "w") as o:
     w = csv.writer(o, quoting=csv.QUOTE_ALL)
