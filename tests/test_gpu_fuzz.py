@@ -181,3 +181,51 @@ def test_random_backward_adjoint_identity(seed):
     scale = sum((g.double().abs() * o.double().abs()).sum() for g, o in zip(gs, fu)) + 1.0
     rel = (lhs - rhs).abs() / scale
     assert rel < (2e-5 if dt == torch.float32 else 1e-12), f"{fn} {c}: <g,F(u)>={lhs.item()} <F^T g,u>={rhs.item()} rel={rel.item()} [{F.last_bwd_kernel()}]"
+
+
+N_SEQ = 300
+
+
+@pytest.mark.parametrize("seed", range(N_SEQ))
+def test_random_seq_family_bit_exact(seed):
+    """The SEQ family walks time exactly as the reference loops do: GAE, TD(lambda) (rolling and rolling_gamma=False) and TD(1)
+    must equal the oracle -- itself pinned bit for bit to the reference -- BIT FOR BIT on random shapes, time dims, coefficient
+    forms (same dtype as the values) and mask regimes."""
+    c = _case(20_000 + seed)
+    fn = ["gae", "td_lambda", "td1", "td_lambda_fixed", "td1_fixed"][seed % 5]
+    shape, dt, kw = c["shape"], c["dtype"], {"time_dim": c["time_dim"]}
+    if fn.endswith("_fixed"):   # O(T^2): keep the rows short
+        td = c["td"]
+        if shape[td] > 300:
+            shape = shape[:td] + (37,) + shape[td + 1:]
+            c = dict(c, shape=shape)
+    gen = torch.Generator().manual_seed(7000 + seed)
+    mk = lambda: torch.randn(shape, generator=gen, dtype=torch.float64).to(dt)
+    r, v, nv = mk(), mk(), mk()
+    done, term = _masks(c, gen)
+    gform = "full" if fn.endswith("_fixed") else c["gform"]
+    gamma = _coef(gform, 0.97, shape, dt, gen)
+    lmbda = _coef(c["lform"], 0.93, shape, dt, gen)
+    cu = lambda x: x.to(DEV) if isinstance(x, torch.Tensor) else x
+    dd, dtm, dc, tc = cu(done), cu(term), done.contiguous(), term.contiguous()
+    td_arg = c["time_dim"]
+    if fn == "gae":
+        ea, evt = O.gae(gamma, lmbda, v, nv, r, dc, tc, **kw)
+        call = F._prepare_gae(cu(gamma), cu(lmbda), cu(v), cu(nv), cu(r), dd, dtm, td_arg)
+        a, vt, _ = F._launch_gae(call, algo=F.ALGO_SEQ)
+        assert "seq" in F.last_kernel()
+        assert torch.equal(a.cpu(), ea) and torch.equal(vt.cpu(), evt), f"{c}"
+    elif fn.startswith("td_lambda"):
+        rolling = None if fn == "td_lambda" else False
+        e = O.td_lambda(gamma, lmbda, nv, r, dc, tc, rolling, **kw)
+        call = F._prepare_td_lambda(cu(gamma), cu(lmbda), cu(nv), cu(r), dd, dtm, rolling, td_arg)
+        out = F._launch_td_lambda(call, nv.dtype, algo=F.ALGO_SEQ)
+        assert "seq" in F.last_kernel()
+        assert torch.equal(out.cpu(), e), f"{c}: max abs diff {(out.cpu() - e).abs().max().item()}"
+    else:
+        rolling = None if fn == "td1" else False
+        e = O.td1(gamma, nv, r, dc, tc, rolling, **kw)
+        call = F._prepare_td1(cu(gamma), cu(nv), cu(r), dd, dtm, rolling, td_arg)
+        out = F._launch_td1(call, nv.dtype, algo=F.ALGO_SEQ)
+        assert "seq" in F.last_kernel()
+        assert torch.equal(out.cpu(), e), f"{c}: max abs diff {(out.cpu() - e).abs().max().item()}"
