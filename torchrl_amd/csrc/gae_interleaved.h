@@ -36,6 +36,9 @@ struct GaePreparedOp {  // what scan_chunk needs of an estimator whose per-step 
 // Where the 9.6 us go (variants built with the parts removed): streaming alone (loads, delta, stores; no LDS, no scan) 7.4 us;
 // plus both LDS turns 7.8; plus the scan 9.6 -- of which 0.55 us is the scan's cross-wave stage (LDS + barrier: rows of 25
 // lanes straddle waves) and the rest VALU issue of the DPP steps (about 150 instructions per wave and chunk).
+// A variant with every row in its own aligned power-of-two lane group (no row crosses a wave: no cross-wave stage, no
+// hard-reset flag; 5- or 8-wave blocks, 25 of 32 lanes busy in the row phase) was built and measured: 11.4 - 15.7 us at C3
+// against 9.5 -- the idle lanes and the fewer resident chunks cost more than the stage it removes.  Dropped.
 #ifndef GIL_WAVES
 #define GIL_WAVES 4
 #endif
