@@ -5,7 +5,11 @@ import sys
 
 import torch
 
-from torchrl_amd.objectives.value import functional as F
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torchrl_amd.objectives.value import functional as F  # noqa: E402
 
 DEV = "cuda:0"
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
