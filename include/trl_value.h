@@ -26,7 +26,11 @@
  *    (no FMA contraction).
  *  - Return value: TRL_OK or an error code; `trl_last_error()` gives the message of the
  *    last failure on the calling thread.  The host wrapper maps them to the reference's
- *    Python exceptions.
+ *    Python exceptions.  One code is a WARNING, not a failure: TRL_WARN_FUSED_DEGRADED means the call did
+ *    everything it was asked to (outputs are valid) and reports, once, that the single-launch route has been
+ *    switched off on this GPU (see trl_fused_degraded below).
+ *  - The `*_cpu` entry points (ABI 7) take HOST pointers, run on the calling thread plus a few worker threads and
+ *    return when the outputs are written: the same estimators for tensors that live in host memory.
  */
 #ifndef TRL_VALUE_H
 #define TRL_VALUE_H
@@ -38,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TRL_ABI_VERSION 6
+#define TRL_ABI_VERSION 7
 
 enum { TRL_F32 = 0, TRL_F64 = 1 };
 
@@ -47,7 +51,9 @@ enum {
     TRL_ERR_INVALID_ARGUMENT = 1, /* null pointer, non-positive size, bad dtype/algo */
     TRL_ERR_UNSUPPORTED = 2,      /* combination not implemented by the chosen algorithm */
     TRL_ERR_WORKSPACE = 3,        /* workspace missing or too small */
-    TRL_ERR_LAUNCH = 4            /* HIP reported a launch error */
+    TRL_ERR_LAUNCH = 4,           /* HIP reported a launch error */
+    TRL_WARN_FUSED_DEGRADED = 100 /* NOT a failure: the call completed; reported once by the first call that notices that
+                                     an earlier single-launch GAE + normalise gave up (trl_fused_degraded) */
 };
 
 /* Kernel family.  AUTO picks by shape. */
@@ -80,9 +86,22 @@ size_t trl_workspace_bytes(int64_t O, int64_t T, int64_t I);
 /* 1 if a single-launch (FUSED) call on this workspace ever gave up waiting for its other blocks (its
  * grid of #CUs persistent blocks must be co-resident: a GPU shared with other long-running kernels
  * can starve it; the wait is bounded at 1 s, the advantage is then written UN-NORMALISED -- finite, never
- * NaN -- and the next estimator call of this process returns TRL_ERR_LAUNCH without a sync), 0 if not, -1 on
- * error.  Synchronises the device. */
+ * NaN -- and the process degrades by itself, see trl_fused_degraded), 0 if not, -1 on error.  Synchronises the device.
+ * workspace == NULL (ABI 7): the static scratch of trl_gae_normalize_fwd_noalloc on the current device; its error word is
+ * read AND cleared (nobody else can reach it), and a set word degrades the device as the host flag does.  Callers of the
+ * no-alloc entry point have no host flag (allocating it is an allocation): they learn of a give-up from this call, or from
+ * `stats` (NaN sum / sumsq on a give-up). */
 int trl_workspace_error(const void *workspace);
+/* Failure semantics of the single-launch route (ABI 7).  A fused launch that gives up raises a word in pinned host memory
+ * (allocated by the first fused launch of trl_gae_normalize_fwd / _xchg_fwd on a device).  The NEXT entry-point call on
+ * that GPU -- any estimator, trl_normalize -- notices it without synchronising and marks the device DEGRADED: from then on
+ * TRL_ALGO_AUTO runs GAE + normalise as two launches (scan + scale pass; no co-residency needed, ~2x the time at
+ * [65536 x 32]).  That call does its own work and returns TRL_WARN_FUSED_DEGRADED once; later calls return TRL_OK.
+ * Only an explicit TRL_ALGO_FUSED request fails (TRL_ERR_LAUNCH, on the call that notices the give-up).
+ * trl_fused_degraded(): 1 if the current device is degraded, else 0.  trl_fused_reset(): re-arms the single launch on the
+ * current device (the caller knows the GPU is its own again). */
+int trl_fused_degraded(void);
+int trl_fused_reset(void);
 
 /*
  * Generalized advantage estimate.
@@ -363,7 +382,8 @@ int trl_standardize_grouped(void *stream, int dtype, const void *x, int64_t oute
  * trl_xchg_allreduce_stats leaves NaN statistics: trl_xchg_error(comm) (synchronises the device) returns 1.
  * In trl_gae_normalize_xchg_fwd's single launch a rank whose own gather gave up sends NaN moments, so every
  * rank sees the failure; each then writes the UN-NORMALISED advantage, sets its error words and raises the
- * host flag (the next estimator call returns TRL_ERR_LAUNCH), as trl_gae_normalize_fwd does on one GPU.
+ * host flag (the next estimator call degrades the device and returns TRL_WARN_FUSED_DEGRADED), as
+ * trl_gae_normalize_fwd does on one GPU.
  * trl_gae_normalize_xchg_fwd = trl_gae_normalize_fwd on a batch sharded over the comm's ranks: the
  * moments are summed over all ranks INSIDE the launch (FUSED family: after the in-launch gather of
  * the block moments, block 0 stores this GPU's totals into the peers' mailboxes and every block

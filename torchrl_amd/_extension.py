@@ -19,7 +19,7 @@ import warnings
 _LIB_NAME = "libtrl_value.so"
 # TRL_VALUE_LIB: development switch (kernel variants built beside the product library); unset in normal use
 _LIB_PATH = os.environ.get("TRL_VALUE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 EXTENSION_WARNING = (
     f"Failed to load the torchrl_amd HIP library ({_LIB_PATH}). The value estimators "
@@ -45,6 +45,8 @@ _PROTOTYPES = {
     "trl_last_kernel": (ctypes.c_char_p, []),
     "trl_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "trl_workspace_error": (_int, [_vp]),
+    "trl_fused_degraded": (_int, []),
+    "trl_fused_reset": (_int, []),
     "trl_gae_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _dbl,
                            _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _int]),
     "trl_gae_normalize_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _dbl,
@@ -168,8 +170,14 @@ class TrlError(RuntimeError):
     """A C-ABI call returned a non-zero status."""
 
 
+WARN_FUSED_DEGRADED = 100  # include/trl_value.h: the call completed; the single-launch route was switched off on this GPU
+
+
 def check(status: int, lib=None):
     if status != 0:
         lib = lib or get_lib()
         msg = lib.trl_last_error().decode("utf-8", "replace")
+        if status == WARN_FUSED_DEGRADED:
+            warnings.warn(f"torchrl_amd: {msg}", RuntimeWarning, stacklevel=3)
+            return
         raise TrlError(f"torchrl_amd native call failed (status {status}): {msg}")

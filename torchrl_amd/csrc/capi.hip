@@ -69,16 +69,26 @@ void *lb_region(void *workspace, size_t workspace_bytes, i64 O, i64 T, i64 I, si
 
 // ---- host-visible failure flag of the single-launch (FUSED) path ----------------------------------------------------------
 // A fused launch whose persistent blocks were not co-resident gives up after a bounded wait, leaves the advantage
-// un-normalised and raises a word in pinned host memory; the next entry-point call on that GPU sees it WITHOUT
-// synchronising anything and fails with TRL_ERR_LAUNCH (then clears it): a training loop stops one step later instead of
-// training on bad advantages.  One word per device, allocated on the first fused launch (never by the no-alloc entry point).
+// un-normalised and raises a word in pinned host memory.  The next entry-point call on that GPU sees it WITHOUT
+// synchronising anything and DEGRADES the device by itself: from then on TRL_ALGO_AUTO takes the two-launch route (scan +
+// scale pass: no co-residency requirement) instead of the single launch, and that call -- after doing its own work --
+// returns TRL_WARN_FUSED_DEGRADED once (python: one RuntimeWarning).  Only an explicit TRL_ALGO_FUSED request still fails
+// with TRL_ERR_LAUNCH.  trl_fused_reset() re-arms the single launch.  One word per device, allocated on the first fused
+// launch (never by the no-alloc entry point).
 static unsigned *g_flag_host[64] = {nullptr};
 static unsigned *g_flag_dev[64] = {nullptr};
+static bool g_fused_degraded[64] = {false};
 static std::mutex g_flag_mu;
 
-static unsigned *fused_flag(bool may_allocate) {
+static int current_device() {
     int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    return dev;
+}
+
+static unsigned *fused_flag(bool may_allocate) {
+    const int dev = current_device();
+    if (dev < 0) return nullptr;
     std::lock_guard<std::mutex> lock(g_flag_mu);
     if (!g_flag_dev[dev] && may_allocate) {
         void *h = nullptr, *d = nullptr;
@@ -91,20 +101,31 @@ static unsigned *fused_flag(bool may_allocate) {
     return g_flag_dev[dev];
 }
 
-// nonzero (and cleared) if a fused launch on the current device gave up since the last look
-static int take_fused_failure() {
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+// true (flag cleared, device marked degraded) if a fused launch on the current device gave up since the last look
+static bool observe_fused_failure() {
+    const int dev = current_device();
+    if (dev < 0) return false;
     volatile unsigned *h = g_flag_host[dev];
-    if (!h || *h == 0u) return 0;
+    if (!h || *h == 0u) return false;
     *h = 0u;
-    return 1;
+    g_fused_degraded[dev] = true;
+    return true;
 }
 
-static int report_fused_failure(const char *fn) {
-    return fail(TRL_ERR_LAUNCH, "%s: an EARLIER single-launch GAE + normalise call on this GPU gave up waiting for its other blocks "
-                "(its persistent grid was not co-resident: another kernel held compute units); that call left the advantage "
-                "UN-NORMALISED.  Run the fused step alone on the GPU or pass TRL_ALGO_SCAN.", fn);
+static bool fused_degraded() {
+    const int dev = current_device();
+    return dev >= 0 && g_fused_degraded[dev];
+}
+
+static const char kGaveUpText[] =
+    "an EARLIER single-launch GAE + normalise call on this GPU gave up waiting for its other blocks (its persistent grid was "
+    "not co-resident: another kernel held compute units); that call left the advantage UN-NORMALISED";
+
+// status of a call that did its work: TRL_OK, or -- once, on the call that noticed the give-up -- the degrade warning
+static int done_ok(const char *fn, bool saw_failure) {
+    if (!saw_failure) return TRL_OK;
+    return fail(TRL_WARN_FUSED_DEGRADED, "%s: completed, but %s.  TRL_ALGO_AUTO now uses the two-launch route on this GPU "
+                "(trl_fused_reset() re-arms the single launch).", fn, kGaveUpText);
 }
 
 // Shifted value layout: next_state_value == NULL, state_value is the (O, T + 1, I) buffer (trl_value.h).
@@ -156,7 +177,7 @@ static int gae_fwd_impl(void *stream, int val_dtype, int coef_dtype, const void 
                         int64_t O, int64_t T, int64_t I, void *advantage, void *value_target,
                         double *stats, void *workspace, size_t workspace_bytes, int algo, bool want_partials,
                         i64 *npartials_out) {
-    if (take_fused_failure()) return report_fused_failure("trl_gae_fwd");
+    const bool saw_failure = observe_fused_failure();
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_fwd: bad dtype");
     if (int rc = check_dims("trl_gae_fwd", O, T, I)) return rc;
     if (!reward || !state_value || !done || !terminated || !advantage || !value_target)
@@ -197,7 +218,7 @@ static int gae_fwd_impl(void *stream, int val_dtype, int coef_dtype, const void 
     }
     if (npartials_out) *npartials_out = res.npartials;
     g_kernel = res.kernel;
-    return TRL_OK;
+    return done_ok("trl_gae_fwd", saw_failure);
 }
 
 
@@ -312,6 +333,36 @@ extern "C" int trl_vtrace_bwd(void *stream, int val_dtype, int coef_dtype, const
 }
 
 
+// ---- the entry point that allocates nothing -------------------------------------------------------------------------------
+// Callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid it) have no
+// workspace to pass: this variant of trl_gae_normalize_fwd brings its own, a file-scope device array.  Every GPU the library
+// runs on holds its own copy of the array (at its own address) until the process ends; the array's name is a host-side
+// stand-in, so host code only ever uses the per-device address hipGetSymbolAddress returned.
+constexpr size_t kStaticScratchBytes = 2u << 20;  // 2 MiB per GPU: C4 needs 0.33 MB, [1024 x 10000] (look-back records) 1.4 MB
+static __device__ __align__(256) unsigned char g_static_scratch[kStaticScratchBytes];  // zero-initialised at module load
+
+static void *static_scratch_ptr(int *err) {
+    static void *ptrs[64] = {nullptr};  // per device; written once
+    static std::mutex mu;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { *err = 1; return nullptr; }
+    std::lock_guard<std::mutex> lock(mu);
+    if (!ptrs[dev]) {
+        void *p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch));  // the address on the CURRENT device
+        if (e != hipSuccess || !p) { *err = 2; return nullptr; }
+        ptrs[dev] = p;
+    }
+    *err = 0;
+    return ptrs[dev];
+}
+
+static void *static_scratch_ptr_or_null() {
+    int err = 0;
+    return static_scratch_ptr(&err);
+}
+
+
 extern "C" {
 
 int trl_abi_version(void) { return TRL_ABI_VERSION; }
@@ -324,12 +375,35 @@ size_t trl_workspace_bytes(int64_t O, int64_t T, int64_t I) {
 }
 
 int trl_workspace_error(const void *workspace) {
-    if (!workspace) return -1;
     // fused-kernel header: {epoch, error, ...}; the look-back header sits behind the partials and is
     // re-zeroed by every launch, so only the fused word persists
     unsigned words[2] = {0, 0};
+    if (!workspace) {
+        // the static scratch of trl_gae_normalize_fwd_noalloc on the current device: its callers have no other way to learn
+        // of a give-up (that entry point allocates nothing, the pinned host flag included).  Read AND cleared here; a set
+        // word also degrades the device like the host flag does.
+        void *ws = static_scratch_ptr_or_null();
+        if (!ws) return -1;
+        if (hipMemcpy(words, ws, sizeof(words), hipMemcpyDeviceToHost) != hipSuccess) return -1;  // synchronises
+        if (words[1] == 0) return 0;
+        const unsigned zero = 0;
+        if (hipMemcpy((char *)ws + sizeof(unsigned), &zero, sizeof(zero), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        const int dev = current_device();
+        if (dev >= 0) g_fused_degraded[dev] = true;
+        return 1;
+    }
     if (hipMemcpy(words, workspace, sizeof(words), hipMemcpyDeviceToHost) != hipSuccess) return -1;  // synchronises
     return words[1] != 0 ? 1 : 0;
+}
+
+int trl_fused_degraded(void) { return fused_degraded() ? 1 : 0; }
+
+int trl_fused_reset(void) {
+    const int dev = current_device();
+    if (dev < 0) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_fused_reset: no current HIP device (or ordinal >= 64)");
+    g_fused_degraded[dev] = false;
+    if (g_flag_host[dev]) *(volatile unsigned *)g_flag_host[dev] = 0u;
+    return TRL_OK;
 }
 
 int trl_gae_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
@@ -346,7 +420,7 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype, const void *r
                       const uint8_t *done, const uint8_t *terminated, int mask_bcast, const void *gamma_t, const void *lmbda_t,
                       double gamma, double lmbda, int rolling_gamma, int64_t O, int64_t T, int64_t I,
                       void *returns, void *workspace, size_t workspace_bytes, int algo) {
-    if (take_fused_failure()) return report_fused_failure("trl_td_lambda_fwd");
+    const bool saw_failure = observe_fused_failure();
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td_lambda_fwd: bad dtype");
     if (int rc = check_dims("trl_td_lambda_fwd", O, T, I)) return rc;
     if (!reward || !next_state_value || !done || !terminated || !returns)
@@ -375,14 +449,14 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype, const void *r
     if (res.status != 0) return fail(res.status, "trl_td_lambda_fwd: launch rejected (grid too large?)");
     if (int rc = check_launch("trl_td_lambda_fwd")) return rc;
     g_kernel = res.kernel;
-    return TRL_OK;
+    return done_ok("trl_td_lambda_fwd", saw_failure);
 }
 
 int trl_td1_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *next_state_value,
                 const uint8_t *done, const uint8_t *terminated, int mask_bcast, const void *gamma_t, double gamma,
                 int rolling_gamma, int64_t O, int64_t T, int64_t I, void *returns, void *workspace, size_t workspace_bytes,
                 int algo) {
-    if (take_fused_failure()) return report_fused_failure("trl_td1_fwd");
+    const bool saw_failure = observe_fused_failure();
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td1_fwd: bad dtype");
     if (int rc = check_dims("trl_td1_fwd", O, T, I)) return rc;
     if (!reward || !next_state_value || !done || !terminated || !returns)
@@ -410,7 +484,7 @@ int trl_td1_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward,
     if (res.status != 0) return fail(res.status, "trl_td1_fwd: launch rejected (grid too large?)");
     if (int rc = check_launch("trl_td1_fwd")) return rc;
     g_kernel = res.kernel;
-    return TRL_OK;
+    return done_ok("trl_td1_fwd", saw_failure);
 }
 
 int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_pi, const void *log_mu,
@@ -419,7 +493,7 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_
                    double rho_thresh, double c_thresh, const void *rho_thresh_t, const void *c_thresh_t,
                    int64_t O, int64_t T, int64_t I,
                    void *advantage, void *vs, void *workspace, size_t workspace_bytes, int algo) {
-    if (take_fused_failure()) return report_fused_failure("trl_vtrace_fwd");
+    const bool saw_failure = observe_fused_failure();
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_vtrace_fwd: bad dtype");
     if (int rc = check_dims("trl_vtrace_fwd", O, T, I)) return rc;
     if (!log_pi || !log_mu || !state_value || !reward || !done || !terminated || !advantage || !vs)
@@ -449,7 +523,7 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_
     if (res.status != 0) return fail(res.status, "trl_vtrace_fwd: launch rejected (grid too large?)");
     if (int rc = check_launch("trl_vtrace_fwd")) return rc;
     g_kernel = res.kernel;
-    return TRL_OK;
+    return done_ok("trl_vtrace_fwd", saw_failure);
 }
 
 static int gae_normalize_impl(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
@@ -458,7 +532,7 @@ static int gae_normalize_impl(void *stream, int val_dtype, int coef_dtype, const
                               int64_t O, int64_t T, int64_t I, void *advantage, void *value_target, double eps,
                               double *stats, void *workspace, size_t workspace_bytes, void *comm, int algo,
                               bool allocate_flag = true) {
-    if (take_fused_failure()) return report_fused_failure("trl_gae_normalize_fwd");
+    const bool saw_failure = observe_fused_failure();
     if (!dtype_ok(val_dtype) || !dtype_ok(coef_dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_normalize_fwd: bad dtype");
     if (int rc = check_dims("trl_gae_normalize_fwd", O, T, I)) return rc;
     if (!reward || !state_value || !done || !terminated || !advantage || !value_target)
@@ -471,14 +545,18 @@ static int gae_normalize_impl(void *stream, int val_dtype, int coef_dtype, const
     if (algo != TRL_ALGO_AUTO && algo != TRL_ALGO_SCAN && algo != TRL_ALGO_SEQ && algo != TRL_ALGO_FUSED)
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_gae_normalize_fwd: unknown algo %d", algo);
     hipStream_t s = (hipStream_t)stream;
-    if (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_FUSED) {
+    if (saw_failure && algo == TRL_ALGO_FUSED)
+        return fail(TRL_ERR_LAUNCH, "trl_gae_normalize_fwd: %s.  Run the fused step alone on the GPU or pass TRL_ALGO_AUTO / TRL_ALGO_SCAN.",
+                    kGaveUpText);
+    // AUTO on a degraded device (a fused launch gave up there): the two-launch route, which needs no co-residency
+    if ((algo == TRL_ALGO_AUTO && !fused_degraded()) || algo == TRL_ALGO_FUSED) {
         GaeArgs a{reward, state_value, next_state_value, done, terminated, gamma_t, lg_t, gamma, lmbda, lg,
                   O, T, I, advantage, value_target, nullptr, 0};
         LaunchResult res = launch_gae_fused(s, val_dtype, coef_dtype, a, eps, workspace, stats, comm, fused_flag(allocate_flag));
         if (res.status == 0) {
             if (int rc = check_launch("trl_gae_normalize_fwd(fused)")) return rc;
             g_kernel = comm ? "gae_fused_xchg" : res.kernel;
-            return TRL_OK;
+            return done_ok("trl_gae_normalize_fwd", saw_failure);
         }
         if (res.status != TRL_ERR_UNSUPPORTED) return fail(res.status, "trl_gae_normalize_fwd: fused launch rejected");
         if (algo == TRL_ALGO_FUSED)
@@ -501,17 +579,19 @@ static int gae_normalize_impl(void *stream, int val_dtype, int coef_dtype, const
                                            advantage, stats, 0);
             if (int rc = check_launch("trl_gae_normalize_fwd(normalize)")) return rc;
             g_kernel = "normalize";
-            return TRL_OK;
+            return done_ok("trl_gae_normalize_fwd", saw_failure);
         }
         launch_reduce_partials(s, partials, np, (double)O * (double)T * (double)I, st);
         if (int rc = check_launch("trl_gae_normalize_fwd(stats)")) return rc;
-        return trl_normalize(stream, val_dtype, advantage, O * T * I, st, eps, advantage);
+        if (int rc = trl_normalize(stream, val_dtype, advantage, O * T * I, st, eps, advantage)) return rc;
+        return done_ok("trl_gae_normalize_fwd", saw_failure);
     }
     if (int rc = trl_gae_fwd(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated, mask_bcast,
                              gamma_t, lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, st, workspace, workspace_bytes, algo2))
         return rc;
     if (int rc = trl_xchg_allreduce_stats(stream, comm, st)) return rc;
-    return trl_normalize(stream, val_dtype, advantage, O * T * I, st, eps, advantage);
+    if (int rc = trl_normalize(stream, val_dtype, advantage, O * T * I, st, eps, advantage)) return rc;
+    return done_ok("trl_gae_normalize_fwd", saw_failure);
 }
 
 int trl_gae_normalize_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward, const void *state_value,
@@ -522,30 +602,6 @@ int trl_gae_normalize_fwd(void *stream, int val_dtype, int coef_dtype, const voi
     return gae_normalize_impl(stream, val_dtype, coef_dtype, reward, state_value, next_state_value, done, terminated,
                               mask_bcast, gamma_t, lg_t, gamma, lmbda, lg, O, T, I, advantage, value_target, eps, stats, workspace,
                               workspace_bytes, nullptr, algo);
-}
-
-// ---- the entry point that allocates nothing -------------------------------------------------------------------------------
-// Callers that cannot call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid it) have no
-// workspace to pass: this variant of trl_gae_normalize_fwd brings its own, a file-scope device array.  Every GPU the library
-// runs on holds its own copy of the array (at its own address) until the process ends; the array's name is a host-side
-// stand-in, so host code only ever uses the per-device address hipGetSymbolAddress returned.
-constexpr size_t kStaticScratchBytes = 2u << 20;  // 2 MiB per GPU: C4 needs 0.33 MB, [1024 x 10000] (look-back records) 1.4 MB
-static __device__ __align__(256) unsigned char g_static_scratch[kStaticScratchBytes];  // zero-initialised at module load
-
-static void *static_scratch_ptr(int *err) {
-    static void *ptrs[64] = {nullptr};  // per device; written once
-    static std::mutex mu;
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { *err = 1; return nullptr; }
-    std::lock_guard<std::mutex> lock(mu);
-    if (!ptrs[dev]) {
-        void *p = nullptr;
-        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch));  // the address on the CURRENT device
-        if (e != hipSuccess || !p) { *err = 2; return nullptr; }
-        ptrs[dev] = p;
-    }
-    *err = 0;
-    return ptrs[dev];
 }
 
 size_t trl_static_scratch_bytes(void) { return kStaticScratchBytes; }
@@ -582,13 +638,13 @@ int trl_gae_normalize_xchg_fwd(void *stream, int val_dtype, int coef_dtype, cons
 }
 
 int trl_normalize(void *stream, int dtype, const void *x, int64_t n, const double *stats, double eps, void *out) {
-    if (take_fused_failure()) return report_fused_failure("trl_normalize");
+    const bool saw_failure = observe_fused_failure();
     if (!dtype_ok(dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_normalize: bad dtype");
     if (n <= 0 || !x || !out || !stats) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_normalize: null pointer or n <= 0");
     launch_normalize((hipStream_t)stream, dtype, x, n, stats, eps, out);
     if (int rc = check_launch("trl_normalize")) return rc;
     g_kernel = "normalize";
-    return TRL_OK;
+    return done_ok("trl_normalize", saw_failure);
 }
 
 int trl_standardize(void *stream, int dtype, const void *x, int64_t n, double eps, void *out, double *stats,

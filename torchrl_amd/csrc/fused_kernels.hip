@@ -12,10 +12,13 @@
 //   * value_target is stored as soon as a chunk is done (stores issued before the publish cost
 //     nothing; anything issued between publish and gather delays the polls); the advantages stay
 //     in registers;
-//   * each block publishes its fp64 {sum, sumsq} as two 8-byte granules {value | 8-bit epoch tag}
-//     with write-through (agent-scope) stores; wave 0 of every block sweeps all blocks' granules
-//     with agent-scope loads until every tag matches (no fences, no atomics, no counters), sums
-//     them in a fixed order (bitwise reproducible) and broadcasts mean / std through LDS;
+//   * each block publishes its fp64 {sum, sumsq} as ONE 16-byte granule {sum | tag, sumsq | tag} (8-bit epoch tag in
+//     the low mantissa bits of each half) with one write-through 16-byte store per replica into a PACKED array
+//     (16 bytes per block, 8 replicas); wave 0 of every block sweeps its replica -- 4 KB for 256 blocks, four
+//     coalesced 16-byte sc1 loads per lane and round -- until every tag matches (no fences, no atomics, no
+//     counters), sums them in a fixed order (bitwise reproducible) and broadcasts mean / std through LDS
+//     (round 3: last publish -> last gathered 2.1 -> 1.6 us at C4 against one 128-byte line per block polled with
+//     8-byte loads, 7.95 -> 7.45 us per launch; tools/kbench/kfused3.hip, kxchg.hip);
 //   * the normalised advantages are written: 22 B of HBM traffic per transition in total, the
 //     algorithmic minimum.
 //   * both outputs leave with WRITE-THROUGH 16-byte stores (sc1): nothing is left dirty in the L2s, so the
@@ -26,8 +29,10 @@
 // The caller zero-fills the workspace once; afterwards only this library touches it.  Each
 // launch tags its granules with (epoch+1) & 0xff and block 0 bumps the epoch when its own sweep
 // has completed (every block has read the epoch by then).  All slots are rewritten by every
-// launch (the grid is always #CUs blocks), so a stale tag can never match.  Two launches that
-// share a workspace must not overlap (same stream, or external ordering).
+// launch (the grid is always #CUs blocks), so a stale tag can never match; a block that GIVES UP re-tags its own
+// granules with the previous launch's tag before it exits, so that nothing it published can match the next launch's
+// tag either (blocks that start after block 0 has bumped the epoch publish with the tag the next launch will use).
+// Two launches that share a workspace must not overlap (same stream, or external ordering).
 // Every spin is bounded (1 s wall clock).  A launch that gives up (its blocks were not co-resident: something else
 // held CUs) writes the UN-NORMALISED advantage, sets the workspace's error word and raises the host-visible flag
 // (capi.hip: the next call on this GPU returns TRL_ERR_LAUNCH) -- never NaNs, never silently.
@@ -47,11 +52,36 @@ struct FusedWs {
     unsigned epoch;
     unsigned error;
     unsigned pad[62];
-    unsigned long long slots[1];  // kMaxBlocks granule pairs, kSlotStride 8-byte units apart
+    unsigned long long slots[1];  // kSlotReplicas packed arrays of gridDim.x 16-byte granules
 };
-constexpr int kSlotStride = 16;  // one 128-byte line per block: the polls of different blocks do not share a line
-constexpr int kSlotReplicas = 4;
-static_assert(256 + (size_t)kSlotReplicas * kMaxBlocks * kSlotStride * 8 <= kFusedWsBytes, "workspace header");
+// Packed granules, 8 replicas (block b sweeps replica b % 8).  Measured at C4 (kfused3.hip): 1 / 4 / 8 / 16 / 32 replicas
+// 7.81 / 7.48 / 7.45 / 7.49 / 7.58 us per launch; one 128-byte line per block (round 2) 7.95; line strides of 256 B - 16 KB
+// no better; two-level gathers (16 x 16, 8 x 32 groups) 7.5 - 7.7; two poll rounds in flight: slower (kxchg.hip).
+constexpr int kSlotReplicas = 8;
+static_assert(256 + (size_t)kSlotReplicas * kMaxBlocks * 16 <= kFusedWsBytes, "workspace header");
+
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+// one write-through 16-byte store (the s_nop: see store_wt)
+__device__ __forceinline__ void store_granule(unsigned long long *p, unsigned long long a, unsigned long long b) {
+    u64x2 v = {a, b};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+// four agent-scope 16-byte loads issued together, one wait (sc1: served from the memory side, never a stale L2 line)
+__device__ __forceinline__ void load_granules4(const unsigned long long *p0, const unsigned long long *p1, const unsigned long long *p2,
+                                               const unsigned long long *p3, u64x2 &v0, u64x2 &v1, u64x2 &v2, u64x2 &v3) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc1\n\t"
+        "global_load_dwordx4 %1, %5, off sc1\n\t"
+        "global_load_dwordx4 %2, %6, off sc1\n\t"
+        "global_load_dwordx4 %3, %7, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+        : "memory");
+}
+__device__ __forceinline__ bool granule_ok(const u64x2 &v, unsigned tag) {
+    return ((unsigned)(v.x & 0xffull) == tag) && ((unsigned)(v.y & 0xffull) == tag);
+}
 
 struct FusedGeom {
     i64 O, T;
@@ -166,49 +196,36 @@ __global__ __launch_bounds__(kFusedThreads) void gae_fused_kernel(typename Op::A
             bss += red[2 * k + 1];
         }
         __builtin_amdgcn_s_setprio(3);  // the publish and the polls go ahead of the other waves' traffic (8.25 -> 8.18 us)
-        // kSlotReplicas copies of every block's granules (lane r writes copy r): the blocks that poll one line drop
-        // from #blocks to #blocks / kSlotReplicas (9.25 -> 9.12 us at C4; 2 / 4 / 8 copies measured, 4 is enough)
+        const int G = (int)gridDim.x;
         constexpr int kRep = kSlotReplicas;
-        const size_t rep_off = (size_t)(blockIdx.x % kRep) * gridDim.x * kSlotStride;
-        if (lane < kRep) {
-            unsigned long long *sl = ws->slots + ((size_t)lane * gridDim.x + blockIdx.x) * kSlotStride;
-            __hip_atomic_store(sl, tag_bits(bs, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sl + 1, tag_bits(bss, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // lane l gathers blocks l, l+64, ...: only the granules still missing are re-polled
-        constexpr int kPer = kMaxBlocks / kWave;
-        unsigned long long vs[kPer], vq[kPer];
-        bool got[kPer];
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) got[j] = lane + kWave * j >= (int)gridDim.x;
+        if (lane < kRep) store_granule(ws->slots + ((size_t)lane * G + blockIdx.x) * 2, tag_bits(bs, tag), tag_bits(bss, tag));
+        // lane l gathers blocks l, l + 64, ... of its replica: every round re-reads the whole array (4 KB at 256 blocks;
+        // re-polling only the missing granules saves nothing on coalesced loads)
+        const unsigned long long *rep = ws->slots + (size_t)(blockIdx.x % kRep) * G * 2;
+        const int i0 = lane, i1 = lane + 64, i2 = lane + 128, i3 = lane + 192;
+        auto at = [&](int i) { return rep + (size_t)(i < G ? i : G - 1) * 2; };  // lanes past the grid re-read the last granule
+        u64x2 v[8] = {};
         const unsigned long long t_start = wall_clock64();
         bool ok;
         for (;;) {
-            ok = true;
-#pragma unroll
-            for (int j = 0; j < kPer; ++j) {
-                if (!got[j]) {
-                    const unsigned long long *sl = ws->slots + rep_off + (size_t)(lane + kWave * j) * kSlotStride;
-                    vs[j] = __hip_atomic_load(sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    vq[j] = __hip_atomic_load(sl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < kPer; ++j) {
-                if (!got[j]) got[j] = ((unsigned)(vs[j] & 0xffull) == tag) && ((unsigned)(vq[j] & 0xffull) == tag);
-                ok = ok && got[j];
+            load_granules4(at(i0), at(i1), at(i2), at(i3), v[0], v[1], v[2], v[3]);
+            ok = granule_ok(v[0], tag) && granule_ok(v[1], tag) && granule_ok(v[2], tag) && granule_ok(v[3], tag);
+            if (G > 4 * kWave) {  // grids of 257 - 512 blocks (kMaxBlocks)
+                load_granules4(at(i0 + 256), at(i1 + 256), at(i2 + 256), at(i3 + 256), v[4], v[5], v[6], v[7]);
+                ok = ok && granule_ok(v[4], tag) && granule_ok(v[5], tag) && granule_ok(v[6], tag) && granule_ok(v[7], tag);
             }
             if (__all(ok)) break;
             if (wall_clock64() - t_start > 100000000ull) break;  // 1 s at 100 MHz: give up loudly
-            // no sleep between rounds (sleep 1 / 4: +0.03 / +0.1 us); two or three poll rounds in flight (also of the
-            // missing granules only): 16 - 23 us -- extra polls slow the publishes down
+            // no sleep between rounds (sleep 1 / 4: +0.03 / +0.1 us); a second round in flight: +0.1 us (kxchg.hip)
         }
         __builtin_amdgcn_s_setprio(0);
         const bool all_ok = __all(ok);
+        if (!all_ok && lane < kRep)  // nothing this block published may match the NEXT launch's tag (see the header comment)
+            store_granule(ws->slots + ((size_t)lane * G + blockIdx.x) * 2, tag_bits(bs, (tag - 1u) & 0xffu), tag_bits(bss, (tag - 1u) & 0xffu));
         double acc = 0.0, acq = 0.0;
 #pragma unroll
-        for (int j = 0; j < kPer; ++j)
-            if (lane + kWave * j < (int)gridDim.x) { acc += untag(vs[j]); acq += untag(vq[j]); }
+        for (int j = 0; j < 8; ++j)
+            if (lane + kWave * j < G) { acc += untag(v[j].x); acq += untag(v[j].y); }
         acc = wave_sum(acc);
         double tot_ss = wave_sum(acq);
         double tot_n = geo.n_total;

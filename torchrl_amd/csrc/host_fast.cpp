@@ -156,6 +156,25 @@ bool empty_like(const at::Tensor &ref, at::ScalarType dt, at::Tensor &out) {
     }
 }
 
+// status of a C-ABI call: 0 = go on; the degrade warning = emit a RuntimeWarning and go on (the outputs are valid); anything
+// else is handed to python as an int (python raises TrlError with trl_last_error()).  Returns false when the caller must
+// return `*ret` (an int object, or nullptr with a python error set because warnings are errors).
+bool call_ok(int rc, PyObject **ret) {
+    if (rc == 0) return true;
+    if (rc == TRL_WARN_FUSED_DEGRADED) {
+        if (PyErr_WarnEx(PyExc_RuntimeWarning,
+                         "torchrl_amd: an earlier single-launch GAE + normalise call on this GPU gave up waiting for its other blocks "
+                         "and left its advantage UN-NORMALISED; GAE + normalise now takes the two-launch route on this GPU "
+                         "(functional.fused_reset() re-arms the single launch)", 1) < 0) {
+            *ret = nullptr;
+            return false;
+        }
+        return true;
+    }
+    *ret = PyLong_FromLong(rc);
+    return false;
+}
+
 PyObject *pair(at::Tensor &&a, at::Tensor &&b) {
     PyObject *out = PyTuple_New(2);
     if (!out) return nullptr;
@@ -266,7 +285,8 @@ PyObject *py_gae(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
         rc = g_gae_fwd((void *)c.stream, c.vdt, cdt, r.data_ptr(), sv.data_ptr(), nsv.data_ptr(), (const uint8_t *)done.data_ptr(),
                        (const uint8_t *)term.data_ptr(), c.bcast, nullptr, nullptr, g_val, 0.0, lg_val, c.O, c.T, c.I, adv.data_ptr(),
                        vt.data_ptr(), nullptr, (void *)ws_ptr, ws_bytes, (int)algo);
-    if (rc) return PyLong_FromLong(rc);
+    PyObject *ret = nullptr;
+    if (!call_ok(rc, &ret)) return ret;
     return pair(std::move(adv), std::move(vt));
 }
 
@@ -302,7 +322,8 @@ PyObject *py_td_lambda(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
     const int rc = g_td_lambda((void *)c.stream, c.vdt, c.vdt, r.data_ptr(), nsv.data_ptr(), (const uint8_t *)done.data_ptr(),
                                (const uint8_t *)term.data_ptr(), c.bcast, nullptr, nullptr, g_val, l_val, 1, c.O, c.T, c.I, out.data_ptr(),
                                (void *)ws_ptr, ws_bytes, (int)algo);
-    if (rc) return PyLong_FromLong(rc);
+    PyObject *ret = nullptr;
+    if (!call_ok(rc, &ret)) return ret;
     return THPVariable_Wrap(std::move(out));
 }
 
@@ -345,7 +366,8 @@ PyObject *py_vtrace(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
     const int rc = g_vtrace((void *)c.stream, c.vdt, cdt, lp.data_ptr(), lmu.data_ptr(), sv.data_ptr(), nsv.data_ptr(), r.data_ptr(),
                             (const uint8_t *)done.data_ptr(), (const uint8_t *)term.data_ptr(), c.bcast, nullptr, g_val, rho_hi, c_hi,
                             nullptr, nullptr, c.O, c.T, c.I, adv.data_ptr(), vs.data_ptr(), (void *)ws_ptr, ws_bytes, (int)algo);
-    if (rc) return PyLong_FromLong(rc);
+    PyObject *ret = nullptr;
+    if (!call_ok(rc, &ret)) return ret;
     return pair(std::move(adv), std::move(vs));
 }
 

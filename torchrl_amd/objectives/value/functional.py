@@ -346,12 +346,30 @@ def _workspace(lib, dev, O, T, I):
 
 def workspace_error(device=None) -> bool:
     """True if a single-launch GAE + normalise on ``device``'s current stream ever timed out waiting for its
-    other blocks (the persistent grid needs the whole GPU; such a call leaves the advantage un-normalised and the next
-    estimator call raises TrlError).  Synchronises."""
+    other blocks (the persistent grid needs the whole GPU; such a call leaves the advantage un-normalised, the next
+    estimator call warns once -- RuntimeWarning -- and GAE + normalise takes the two-launch route on that GPU from then
+    on: :func:`fused_degraded`, :func:`fused_reset`).  Synchronises."""
     lib = _extension.get_lib()
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     ws = _WORKSPACES.get((dev.index if dev.index is not None else torch.cuda.current_device(), _stream(dev)))
     return ws is not None and lib.trl_workspace_error(_ptr(ws)) == 1
+
+
+def fused_degraded(device=None) -> bool:
+    """True once a single-launch GAE + normalise call on ``device`` (default: the current one) has given up: the library
+    then runs the step as two launches (scan + scale pass), which need no co-resident grid (include/trl_value.h:
+    trl_fused_degraded).  No synchronisation."""
+    lib = _extension.get_lib()
+    with (torch.cuda.device(device) if device is not None else _NO_GUARD):
+        return lib.trl_fused_degraded() == 1
+
+
+def fused_reset(device=None) -> None:
+    """Re-arm the single-launch route on ``device`` after :func:`fused_degraded` (the caller knows that nothing else
+    holds compute units any more)."""
+    lib = _extension.get_lib()
+    with (torch.cuda.device(device) if device is not None else _NO_GUARD):
+        _extension.check(lib.trl_fused_reset(), lib)
 
 
 def _lookback_workspace(lib, dev, O, T, I):
