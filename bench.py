@@ -2,10 +2,14 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
+    python bench.py --gpus N [--scaling strong|weak]
+
 One "step" is one pass of the hot path over one batch of synthetic rollouts already resident in
 HBM.  N = 1: trl_gae_normalize_fwd -- ONE launch (fused delta + scan + value_target + fp64 moments
-+ in-launch gather + normalisation).  N > 1: every rank owns a full [65536 x 32] batch (weak
-scaling: the env dimension is sharded) and the only exchange is the sum of the 3 fp64 moments.
++ in-launch gather + normalisation).  N > 1, `--scaling strong` (the default; BASELINE config 4): ONE
+[65536 x 32] batch sharded over the ranks along the env dimension, [65536 / N x 32] per GPU.
+`--scaling weak`: every rank owns a full [65536 x 32] batch.  Either way the only exchange is the
+sum of the 3 fp64 moments.
 Preferred route: trl_gae_normalize_xchg_fwd -- still ONE launch per GPU, the moments cross the GPUs
 inside it (peer-to-peer mailbox stores over xGMI); it is validated against the RCCL route on the
 live topology first and used only if every rank agrees.  Other route, always measured beside it:
@@ -36,6 +40,8 @@ GAMMA, LMBDA, EPS = 0.99, 0.95, 1e-4
 BYTES_PER_TRANSITION = 22  # fp32 GAE: 3x4 B + 2x1 B read, 2x4 B written; normalise adds no compulsory traffic
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
 PREROLL_STEPS = 1500       # untimed clock-settle pre-roll (~12 ms of GPU time), outside `warmup`, reported in the line
+KERNEL_BATCHES, KERNEL_BATCH = 5, 200   # kernel_ms = median over 5 batches of 200 back-to-back launches (all batches reported)
+COLD_SETS = 10             # cold leg: rotate over 10 distinct input / output buffer sets, 461 MB > the 256 MiB Infinity Cache
 
 
 def pmc_traffic(kernel_name):
@@ -56,11 +62,11 @@ def pmc_traffic(kernel_name):
     return None, None
 
 
-def make_inputs(dev, seed):
+def make_inputs(dev, seed, envs=O_ENVS):
     import torch
 
     g = torch.Generator(device="cpu").manual_seed(seed)
-    shape = (O_ENVS, T_STEPS, 1)
+    shape = (envs, T_STEPS, 1)
     r, v, nv = (torch.randn(shape, generator=g) for _ in range(3))
     term = torch.rand(shape, generator=g) < 0.01
     done = term | (torch.rand(shape, generator=g) < 0.01)
@@ -131,7 +137,7 @@ def self_launch(args):
         env["TRL_BENCH_REHEARSAL"] = f"{args.gpus} ranks on {ndev} GPU(s)"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
-           "--warmup", str(args.warmup)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+           "--warmup", str(args.warmup), "--scaling", args.scaling] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True)
     line = None
     for ln in p.stdout.splitlines():
@@ -151,6 +157,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: strong = one [65536 x 32] batch sharded over the ranks (BASELINE config 4); weak = a full batch per rank")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold (beyond-Infinity-Cache) leg")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -196,8 +205,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    r, v, nv, done, term = make_inputs(dev, seed=rank)
-    call = F._prepare_gae(GAMMA, LMBDA, v, nv, r, done, term, -2)  # host canonicalisation: views only, no copies
+    strong = dist and args.scaling == "strong"
+    if dist and O_ENVS % world:
+        raise SystemExit(f"bench: the world size must divide {O_ENVS}")
 
     # The step is bound once to fixed buffers (a training loop keeps its rollout buffers in place):
     # the timed region contains the C-ABI calls (kernels) and, on the RCCL route, the collective.
@@ -212,39 +222,56 @@ def main():
         torch.cuda.synchronize()
         return ev[0].elapsed_time(ev[1]) / n
 
-    collective = "none"
-    routes = {}
-    if dist:
-        def all_reduce_stats(st):
-            if backend == "gloo":  # rehearsal: gloo has no device tensors
-                h = st.cpu()
-                td.all_reduce(h)
-                st.copy_(h)
-            else:
-                td.all_reduce(st)
+    exchange = {"tried": False, "ex": None}
 
-        gae = F.prepare_gae_step(call, normalize=False, want_stats=True)
-        norm = F.prepare_normalize(gae.outputs[0], gae.stats, EPS)
+    def get_exchange():
+        """The in-launch mailbox exchange, created once (collective call: every rank) if every rank's probe succeeded."""
+        if not exchange["tried"]:
+            exchange["tried"] = True
+            probes = [None] * world
+            td.all_gather_object(probes, probe_ok)
+            if all(probes):
+                from torchrl_amd.objectives.value.stats_exchange import StatsExchange
 
-        def rccl_step():
-            gae.run()
-            all_reduce_stats(gae.stats)
-            norm.run()
-            return gae.outputs
+                exchange["ex"] = StatsExchange.create(timeout_s=5.0)  # self-tested against the process group's all-reduce
+            elif rank == 0:
+                print(f"bench: exchange route not used (probe results {probes})", file=sys.stderr)
+            if rank == 0 and os.path.exists(probe_store):
+                os.remove(probe_store)
+        return exchange["ex"]
 
-        rccl_step()
-        ref_adv = gae.outputs[0].clone()
-        rccl_name = "all_reduce(3 x f64) over " + ("RCCL" if backend == "nccl" else backend)
-        collective = rccl_name
-        step = rccl_step
-        kernel_step = gae.run
-        probes = [None] * world
-        td.all_gather_object(probes, probe_ok)
-        mailbox_step = None
-        if all(probes):
-            from torchrl_amd.objectives.value.stats_exchange import StatsExchange
+    def run_mode(envs, steps, warmup):
+        """Build the step for `envs` env rows on this rank, measure the dominant kernel and time `steps` steps."""
+        r, v, nv, done, term = make_inputs(dev, seed=rank, envs=envs)
+        call = F._prepare_gae(GAMMA, LMBDA, v, nv, r, done, term, -2)  # host canonicalisation: views only, no copies
+        collective = "none"
+        routes = {}
+        if dist:
+            def all_reduce_stats(st):
+                if backend == "gloo":  # rehearsal: gloo has no device tensors
+                    h = st.cpu()
+                    td.all_reduce(h)
+                    st.copy_(h)
+                else:
+                    td.all_reduce(st)
 
-            ex = StatsExchange.create(timeout_s=5.0)  # self-tested against the process group's all-reduce
+            gae = F.prepare_gae_step(call, normalize=False, want_stats=True)
+            norm = F.prepare_normalize(gae.outputs[0], gae.stats, EPS)
+
+            def rccl_step():
+                gae.run()
+                all_reduce_stats(gae.stats)
+                norm.run()
+                return gae.outputs
+
+            rccl_step()
+            ref_adv = gae.outputs[0].clone()
+            rccl_name = "all_reduce(3 x f64) over " + ("RCCL" if backend == "nccl" else backend)
+            collective = rccl_name
+            step = rccl_step
+            kernel_step = gae.run
+            mailbox_step = None
+            ex = get_exchange()
             good = False
             if ex is not None:
                 fused = F.prepare_gae_step(call, EPS, normalize=True, exchange=ex)
@@ -259,65 +286,80 @@ def main():
                 mailbox_step = fused.run
             elif rank == 0:
                 print(f"bench: exchange route not used (votes {votes}); falling back to {collective}", file=sys.stderr)
-        elif rank == 0:
-            print(f"bench: exchange route not used (probe results {probes}); using {collective}", file=sys.stderr)
-        if rank == 0 and os.path.exists(probe_store):
-            os.remove(probe_store)
-        # both routes, measured beside each other (untimed region; every rank runs the same sequence)
-        for _ in range(20):
-            rccl_step()
-        td.barrier()
-        routes["rccl_all_reduce_ms"] = device_ms(rccl_step, 100)
-        if mailbox_step is not None:
+            # both routes, measured beside each other (untimed region; every rank runs the same sequence)
             for _ in range(20):
-                mailbox_step()
+                rccl_step()
             td.barrier()
-            routes["in_launch_mailbox_ms"] = device_ms(mailbox_step, 200)
-            step = kernel_step = mailbox_step
-            collective = ("in-launch peer-to-peer mailbox exchange (3 x f64 per rank over xGMI), validated against " + rccl_name)
-    else:
-        one = F.prepare_gae_step(call, EPS, normalize=True)  # one launch (FUSED family)
-        step = kernel_step = one.run
-
-    step()
-    kernel_name = F.last_kernel()  # the dominant kernel: the GAE entry point's
-    # untimed clock-settle pre-roll: a short run would otherwise time the kernel while the clocks still ramp
-    for _ in range(PREROLL_STEPS):
-        kernel_step()
-    torch.cuda.synchronize()
-    kernel_ms = device_ms(kernel_step, 200)  # HIP events on the launch stream around back-to-back launches of the dominant kernel
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        td.barrier()
-        torch.cuda.synchronize()
-    # HIP events around the timed steps are informational (timed_region_device_ms_per_step); each record is a marker packet
-    # on the stream and a few microseconds of host time, which a short run would carry as per-step cost: long runs only
-    with_events = args.steps >= 200
-    t0 = time.perf_counter()
-    if with_events:
-        ev[0].record()
-    for k in range(args.steps):
-        step()
-    if with_events:
-        ev[1].record()
-    t_host = time.perf_counter() - t0  # host time to enqueue K steps
-    torch.cuda.synchronize()
-    if dist:
-        td.barrier()
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    timed_ms = ev[0].elapsed_time(ev[1]) / args.steps if with_events else None
-    if dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if backend == "gloo":
-            h = tmax.cpu()
-            td.all_reduce(h, op=td.ReduceOp.MAX)
-            tmax = h
+            routes["rccl_all_reduce_ms"] = device_ms(rccl_step, 100)
+            if mailbox_step is not None:
+                for _ in range(20):
+                    mailbox_step()
+                td.barrier()
+                routes["in_launch_mailbox_ms"] = device_ms(mailbox_step, 200)
+                step = kernel_step = mailbox_step
+                collective = ("in-launch peer-to-peer mailbox exchange (3 x f64 per rank over xGMI), validated against " + rccl_name)
         else:
-            td.all_reduce(tmax, op=td.ReduceOp.MAX)
-        dt = float(tmax.item())
+            one = F.prepare_gae_step(call, EPS, normalize=True)  # one launch (FUSED family)
+            step = kernel_step = one.run
+
+        step()
+        kernel_name = F.last_kernel()  # the dominant kernel: the GAE entry point's
+        # untimed clock-settle pre-roll: a short run would otherwise time the kernel while the clocks still ramp
+        for _ in range(PREROLL_STEPS):
+            kernel_step()
+        torch.cuda.synchronize()
+        # HIP events on the launch stream around back-to-back launches of the dominant kernel: median of 5 batches of 200
+        kernel_batches = sorted(device_ms(kernel_step, KERNEL_BATCH) for _ in range(KERNEL_BATCHES))
+        kernel_ms = kernel_batches[KERNEL_BATCHES // 2]
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+            torch.cuda.synchronize()
+        # HIP events around the timed steps are informational (timed_region_device_ms_per_step); each record is a marker packet
+        # on the stream and a few microseconds of host time, which a short run would carry as per-step cost: long runs only
+        with_events = steps >= 200
+        t0 = time.perf_counter()
+        if with_events:
+            ev[0].record()
+        for k in range(steps):
+            step()
+        if with_events:
+            ev[1].record()
+        t_host = time.perf_counter() - t0  # host time to enqueue K steps
+        torch.cuda.synchronize()
+        if dist:
+            td.barrier()
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        timed_ms = ev[0].elapsed_time(ev[1]) / steps if with_events else None
+        if dist:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            if backend == "gloo":
+                h = tmax.cpu()
+                td.all_reduce(h, op=td.ReduceOp.MAX)
+                tmax = h
+            else:
+                td.all_reduce(tmax, op=td.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return {"envs": envs, "dt": dt, "kernel_ms": kernel_ms, "kernel_batches": kernel_batches, "kernel_name": kernel_name,
+                "routes": routes, "collective": collective, "t_host": t_host, "timed_ms": timed_ms, "inputs": (r, v, nv, done, term)}
+
+    envs = O_ENVS // world if strong else O_ENVS   # env rows this rank owns
+    m = run_mode(envs, args.steps, args.warmup)
+    r, v, nv, done, term = m["inputs"]
+    dt, kernel_ms, kernel_batches, kernel_name = m["dt"], m["kernel_ms"], m["kernel_batches"], m["kernel_name"]
+    routes, collective, t_host, timed_ms = m["routes"], m["collective"], m["t_host"], m["timed_ms"]
+    # N > 1: the other scaling mode beside it (same step count), so that one run documents both curves
+    other = None
+    if dist:
+        o_envs = O_ENVS if strong else O_ENVS // world
+        mo = run_mode(o_envs, args.steps, args.warmup)
+        other = {"scaling": "weak" if strong else "strong", "per_gpu_envs": o_envs, "value": o_envs * T_STEPS * world * args.steps / mo["dt"],
+                 "ms_per_step": mo["dt"] / args.steps * 1e3, "kernel_ms": mo["kernel_ms"], "route_ms_per_step": mo["routes"],
+                 "collective": mo["collective"]}
+        del mo
 
     # the public entry point (host canonicalisation + allocation + the same launch), per call
     entry_point_ms = module_entry_ms = None
@@ -344,42 +386,85 @@ def main():
         torch.cuda.synchronize()
         module_entry_ms = (time.perf_counter() - t1) / 300 * 1e3
 
+    # cold leg (N = 1): the same launch rotating over COLD_SETS distinct input / output buffer sets, so that no byte of a
+    # launch is left in the 256 MiB Infinity Cache by the previous ones -- the DRAM-bound figure beside the warm one --
+    # and, for scale, what a plain device copy (1 read + 1 write, torch) reaches on buffers beyond the cache on this box
+    cold = None
+    if not dist and not args.no_cold:
+        sets = []
+        for k in range(COLD_SETS):
+            ins = make_inputs(dev, seed=1000 + k)
+            ck = F._prepare_gae(GAMMA, LMBDA, ins[1], ins[2], ins[0], ins[3], ins[4], -2)
+            sets.append(F.prepare_gae_step(ck, EPS, normalize=True))
+
+        def cold_round():
+            for st in sets:
+                st.run()
+
+        for _ in range(20):
+            cold_round()
+        cold_batches = sorted(device_ms(cold_round, 20) / COLD_SETS for _ in range(KERNEL_BATCHES))
+        cold_ms = cold_batches[KERNEL_BATCHES // 2]
+        del sets
+        n_copy = 512 * (1 << 20) // 4
+        src, dst = torch.empty(n_copy, device=dev).normal_(), torch.empty(n_copy, device=dev)
+        for _ in range(3):
+            dst.copy_(src)
+        copy_gbs = 8 * n_copy / (device_ms(lambda: dst.copy_(src), 10) * 1e-3) / 1e9
+        del src, dst
+        cold_bytes = O_ENVS * T_STEPS * BYTES_PER_TRANSITION
+        cold = {"kernel_ms": cold_ms, "kernel_ms_batches": cold_batches, "achieved": cold_bytes / (cold_ms * 1e-3) / 1e9,
+                "frac": cold_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "buffer_sets": COLD_SETS,
+                "footprint_bytes": COLD_SETS * O_ENVS * T_STEPS * BYTES_PER_TRANSITION,
+                "copy_ceiling_gbs": copy_gbs, "frac_of_copy_ceiling": cold_bytes / (cold_ms * 1e-3) / 1e9 / copy_gbs,
+                "note": f"same launch rotating over {COLD_SETS} distinct buffer sets (461 MB > 256 MiB Infinity Cache): DRAM-bound; "
+                        "copy_ceiling_gbs = torch device copy of 512 MiB (1 read + 1 write) measured in this run"}
+
     if rank == 0:
-        n_trans = O_ENVS * T_STEPS
+        n_trans = envs * T_STEPS               # transitions one GPU processes per step
+        n_job = n_trans * world                # transitions the whole job processes per step
         achieved = n_trans * BYTES_PER_TRANSITION / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(kernel_name if world == 1 else None)
         out = {
             "metric": "GAE transitions/sec + % HBM roofline at 65536x32",
-            "value": world * n_trans * args.steps / dt,
+            "value": n_job * args.steps / dt,
             "unit": "transitions/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"GAE(gamma={GAMMA},lmbda={LMBDA})+normalise(eps={EPS}) [{O_ENVS} envs x {T_STEPS} steps] fp32 per GPU; "
-                                   f"the 46 MB working set is Infinity-Cache-resident across back-to-back steps",
-                       "per_gpu_transitions": n_trans, "parallelism": f"env-sharded x{world}",
+            "config": {"workload": (f"GAE(gamma={GAMMA},lmbda={LMBDA})+normalise(eps={EPS}) ONE [{O_ENVS} envs x {T_STEPS} steps] fp32 batch sharded "
+                                    f"over {world} GPUs as {world} x [{envs} x {T_STEPS}] (strong scaling, BASELINE config 4)" if strong else
+                                    f"GAE(gamma={GAMMA},lmbda={LMBDA})+normalise(eps={EPS}) [{O_ENVS} envs x {T_STEPS} steps] fp32 per GPU"
+                                    + (" (weak scaling)" if dist else ""))
+                                   + "; the working set is Infinity-Cache-resident across back-to-back steps (roofline.cold: the DRAM-bound leg)",
+                       "per_gpu_transitions": n_trans, "job_transitions": n_job, "parallelism": f"env-sharded x{world}",
                        "collective": collective, "preroll_steps": PREROLL_STEPS},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel_name,
-                         "kernel_ms": kernel_ms, "bytes_per_launch": n_trans * BYTES_PER_TRANSITION,
+                         "kernel_ms": kernel_ms, "kernel_ms_batches": kernel_batches,
+                         "bytes_per_launch": n_trans * BYTES_PER_TRANSITION,
                          "timed_region_device_ms_per_step": timed_ms,
                          "host_enqueue_ms_per_step": t_host / args.steps * 1e3,
-                         "note": "fraction of the 8 TB/s HBM peak; with the working set in the 256 MiB Infinity Cache this is a "
-                                 "fabric / cache roofline, not a DRAM one"},
+                         "note": "fraction of the 8 TB/s HBM peak; kernel_ms = median of 5 batches of 200 back-to-back launches; with the "
+                                 "working set in the 256 MiB Infinity Cache this is a fabric / cache roofline, not a DRAM one -- `cold` is"},
         }
+        if cold is not None:
+            out["roofline"]["cold"] = cold
         if entry_point_ms is not None:
             out["entry_point_ms"] = entry_point_ms
             out["entry_point_host"] = "cxx" if F.host_fast_path() else "python"
             out["module_entry_ms"] = module_entry_ms
         if routes:
             out["config"]["route_ms_per_step"] = routes
+        if other is not None:
+            out["config"]["other_scaling_mode"] = other
         if os.environ.get("TRL_BENCH_REHEARSAL"):
             out["config"]["rehearsal"] = os.environ["TRL_BENCH_REHEARSAL"] + f" over {backend}: control-flow rehearsal, not a scaling number"
         if world == 1 and not args.no_cpu_baseline:

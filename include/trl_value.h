@@ -408,6 +408,68 @@ int trl_gae_normalize_xchg_fwd(void *stream, int val_dtype, int coef_dtype,
                                void *advantage, void *value_target, double eps,
                                double *stats, void *workspace, size_t workspace_bytes, void *comm, int algo);
 
+/*
+ * Host entry points (ABI 7): the same estimators for tensors in HOST memory -- every pointer below is a host pointer,
+ * `stats` included; the call returns when the outputs are written.  The reference runs its estimators on whatever device
+ * the tensors live on (functional.py:163-170 allocates on state_value.device; the CartPole-shaped BASELINE config is a CPU
+ * call), so the drop-in takes CPU tensors too.  Arguments as in the device entry points of the same name, minus stream,
+ * workspace and `algo`: there is one family, the row-sequential walk in the reference's operation order -- the very row
+ * functions of the SEQ kernels (csrc/seq_rows.h) -- so results are bit-identical to TRL_ALGO_SEQ on the GPU (V-trace: up to
+ * libm's exp) and to the reference's loop.  Rows are split over trl_cpu_threads() threads (TRL_CPU_THREADS, else
+ * OMP_NUM_THREADS, else min(cores, 16); jobs under 65536 elements run on the calling thread); the moments are summed in a
+ * fixed order that does not depend on the thread count.  No HIP call is made: they work without a GPU.
+ * trl_td_fixed_bwd has no host counterpart (rolling_gamma=False is differentiable on the GPU only).
+ */
+int trl_cpu_threads(void);
+int trl_set_cpu_threads(int n); /* 0: decide from the environment again */
+int trl_gae_fwd_cpu(int val_dtype, int coef_dtype,
+                    const void *reward, const void *state_value, const void *next_state_value,
+                    const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                    const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
+                    int64_t O, int64_t T, int64_t I, void *advantage, void *value_target, double *stats);
+int trl_gae_normalize_fwd_cpu(int val_dtype, int coef_dtype,
+                              const void *reward, const void *state_value, const void *next_state_value,
+                              const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                              const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
+                              int64_t O, int64_t T, int64_t I, void *advantage, void *value_target, double eps, double *stats);
+int trl_td_lambda_fwd_cpu(int val_dtype, int coef_dtype, const void *reward, const void *next_state_value,
+                          const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                          const void *gamma_t, const void *lmbda_t, double gamma, double lmbda, int rolling_gamma,
+                          int64_t O, int64_t T, int64_t I, void *returns);
+int trl_td1_fwd_cpu(int val_dtype, int coef_dtype, const void *reward, const void *next_state_value,
+                    const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                    const void *gamma_t, double gamma, int rolling_gamma,
+                    int64_t O, int64_t T, int64_t I, void *returns);
+int trl_vtrace_fwd_cpu(int val_dtype, int coef_dtype, const void *log_pi, const void *log_mu,
+                       const void *state_value, const void *next_state_value, const void *reward,
+                       const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                       const void *gamma_t, double gamma, double rho_thresh, double c_thresh,
+                       const void *rho_thresh_t, const void *c_thresh_t,
+                       int64_t O, int64_t T, int64_t I, void *advantage, void *vs);
+int trl_gae_bwd_cpu(int val_dtype, int coef_dtype, const void *grad_advantage, const void *grad_value_target,
+                    const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                    const void *gamma_t, const void *lg_t, double gamma, double lmbda, double lg,
+                    int64_t O, int64_t T, int64_t I, void *d_reward, void *d_state_value, void *d_next_state_value);
+int trl_td_lambda_bwd_cpu(int val_dtype, int coef_dtype, const void *grad_returns,
+                          const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                          const void *gamma_t, const void *lmbda_t, double gamma, double lmbda,
+                          int64_t O, int64_t T, int64_t I, void *d_reward, void *d_next_state_value);
+int trl_td1_bwd_cpu(int val_dtype, int coef_dtype, const void *grad_returns,
+                    const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                    const void *gamma_t, double gamma,
+                    int64_t O, int64_t T, int64_t I, void *d_reward, void *d_next_state_value);
+int trl_vtrace_bwd_cpu(int val_dtype, int coef_dtype, const void *grad_advantage, const void *grad_vs,
+                       const void *log_pi, const void *log_mu,
+                       const void *state_value, const void *next_state_value, const void *reward, const void *vs,
+                       const uint8_t *done, const uint8_t *terminated, int mask_bcast,
+                       const void *gamma_t, double gamma, double rho_thresh, double c_thresh,
+                       const void *rho_thresh_t, const void *c_thresh_t,
+                       int64_t O, int64_t T, int64_t I,
+                       void *d_log_pi, void *d_log_mu, void *d_state_value, void *d_next_state_value, void *d_reward, void *d_gamma_t);
+/* {N, sum, sumsq} of x (host double[3]) / (x - mean) / max(std, eps) from such statistics, as trl_moments / trl_normalize */
+int trl_moments_cpu(int dtype, const void *x, int64_t n, double *stats);
+int trl_normalize_cpu(int dtype, const void *x, int64_t n, const double *stats, double eps, void *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,8 +100,13 @@ def test_random_case_against_oracle(seed):
             a, vt = F.gae_normalized(cu(gamma), cu(lmbda), cu(v), cu(nv), cu(r), dd, dtm, eps=1e-4, **kw)
             torch.testing.assert_close(vt.cpu(), evt, msg=lambda m: f"{info}: {m}", **tol)
             ref = O.normalize(ea.contiguous(), 1e-4).reshape(ea.shape)
-            # the normalised advantage inherits the scan's error divided by std, which is O(1) here
-            ntol = dict(rtol=1e-4, atol=1e-4) if dt == torch.float32 else dict(rtol=1e-10, atol=1e-10)
+            # the bar (1e-5 / 1e-12) holds for the advantage A; the normalised advantage is (A - mean) / max(std, eps), so an
+            # error e in A arrives as e / std: the bar is scaled by 1 / std where std < 1 (random tiny batches of this sweep
+            # can have any std) and is the plain bar otherwise (measured at the BASELINE shapes, std(A) ~ 3 - 5: <= 7e-7 / 3e-14,
+            # profiles/r03_parity_errors.txt).  fp64: the mean / std come from fp64 sums in another order, 1e-12 * amplification
+            amp = max(1.0, 1.0 / max(float(ea.double().std()), 1e-4))
+            base = 1e-5 if dt == torch.float32 else 1e-12
+            ntol = dict(rtol=base, atol=base * amp)
             torch.testing.assert_close(a.cpu(), ref, msg=lambda m: f"{info}: {m}", **ntol)
             return
         f = F.generalized_advantage_estimate if fn == "gae" else F.vec_generalized_advantage_estimate
@@ -125,9 +130,10 @@ def test_random_case_against_oracle(seed):
         lm = torch.rand(shape, generator=gen, dtype=torch.float64).clamp_min(1e-3).log().to(dt)
         ea, evs = O.vtrace(gamma, lp, lm, v, nv, r, dc, tc, 1.0, 0.9, **kw)
         a, vs = F.vtrace_advantage_estimate(cu(gamma), cu(lp), cu(lm), cu(v), cu(nv), cu(r), dd, dtm, 1.0, 0.9, **kw)
+        # device exp vs the host's: an ulp on every importance ratio (measured at C4 / C5: 1.5e-6 mixed error at fp32 on the
+        # scan kernels, 9e-7 on SEQ; 5e-15 at fp64): the north_star bar holds at fp32; fp64 carries the ulp of exp through
+        # products of up to T ratios, 1e-11
         vtol = tol if dt == torch.float32 else dict(rtol=1e-11, atol=1e-11)
-        if dt == torch.float32:
-            vtol = dict(rtol=2e-5, atol=2e-5)   # device expf vs the host's: an ulp or two on every ratio
         torch.testing.assert_close(a.cpu().to(ea.dtype), ea, msg=lambda m: f"{info}: {m}", **vtol)
         torch.testing.assert_close(vs.cpu().to(ea.dtype), evs, msg=lambda m: f"{info}: {m}", **vtol)
 

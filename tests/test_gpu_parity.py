@@ -252,7 +252,8 @@ def test_errors_on_device():
 
 
 FUSED_SHAPES = [(64, 32, 1), (65536, 32, 1), (3000, 32, 1), (37, 100, 1), (5000, 100, 1), (33, 3, 1), (9, 1, 1),
-                (130, 128, 1), (2000, 1024, 1), (5, 7, 1), (100000, 32, 1), (200000, 32, 1)]  # the last two: 5..8 chunks per team
+                (130, 128, 1), (2000, 1024, 1), (5, 7, 1), (100000, 32, 1), (200000, 32, 1),  # the last two: 5..8 chunks per team
+                (32768, 32, 1), (16384, 32, 1), (8192, 32, 1)]  # the per-GPU shards of the [65536 x 32] batch on 2 / 4 / 8 GPUs
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
@@ -269,7 +270,9 @@ def test_fused_gae_normalise_vs_oracle(shape, dtype):
     oadv, ovt = O.gae(0.99, 0.95, v, nv, r, done, term)
     onorm = O.normalize(oadv, 1e-4)
     call = F._prepare_gae(0.99, 0.95, cu(v), cu(nv), cu(r), cu(done), cu(term), -2)
-    t = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=1e-10, atol=1e-10)
+    # north_star's bar.  Measured (profiles/r03_parity_errors.txt, tests/report_parity_errors.py): normalised advantage
+    # 2e-7 .. 7e-7 mixed error at fp32, <= 3e-14 at fp64 (the scan's error divided by std(A) ~ 4, plus the rounding of mean / std)
+    t = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-12, atol=1e-12)
     n_el = shape[0] * shape[1]
     a64 = F._launch_gae(call, algo=F.ALGO_SCAN)[0].double()  # same scan, un-normalised
     ref_st = torch.stack([torch.tensor(float(n_el), device=DEV, dtype=torch.float64), a64.sum(), (a64 * a64).sum()])
@@ -293,7 +296,7 @@ def test_fused_falls_back_when_not_eligible():
     adv, vt = F.gae_normalized(0.99, 0.95, cu(v), cu(nv), cu(r), cu(done), cu(term))
     assert F.last_kernel() == "normalize"
     oadv, ovt = O.gae(0.99, 0.95, v, nv, r, done, term)
-    torch.testing.assert_close(adv.cpu(), O.normalize(oadv, 1e-4), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(adv.cpu(), O.normalize(oadv, 1e-4), rtol=1e-5, atol=1e-5)
     with pytest.raises(RuntimeError, match="FUSED family needs"):
         F._launch_gae_normalize(F._prepare_gae(0.99, 0.95, cu(v), cu(nv), cu(r), cu(done), cu(term), -2), 1e-4, algo=F.ALGO_FUSED)
 
@@ -429,7 +432,7 @@ def test_broadcast_masks_read_in_place(shape, time_dim, dtype):
     adv, vt = F.generalized_advantage_estimate(0.9, 0.9, cu(v), cu(nv), cu(r), dd, tt, time_dim=time_dim)
     check(adv, oadv, False, done)
     nadv, _ = F.gae_normalized(0.9, 0.9, cu(v), cu(nv), cu(r), dd, tt, time_dim=time_dim)
-    torch.testing.assert_close(nadv.cpu(), O.normalize(oadv, 1e-4), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(nadv.cpu(), O.normalize(oadv, 1e-4), rtol=1e-5, atol=1e-5)
     # rolling_gamma=False (O(T^2) SEQ kernel) reads the compact masks too
     if shape[len(shape) + td] <= 50:
         got = F.td_lambda_return_estimate(cu(gam), 0.9, cu(nv), cu(r), dd, tt, rolling_gamma=False, time_dim=time_dim)
@@ -485,7 +488,7 @@ def test_long_rows_with_few_features(shape, time_dim, dtype, bcast):
     check(va, ova, False)
     check(vs, ovs, False)
     nadv, vt2 = F.gae_normalized(cu(gam), 0.9, cu(v), cu(nv), cu(r), dd, tt, time_dim=time_dim)
-    torch.testing.assert_close(nadv.cpu(), O.normalize(oadv, 1e-4), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(nadv.cpu(), O.normalize(oadv, 1e-4), rtol=1e-5, atol=1e-5)
     check(vt2, ovt, False, done)
     # the exact family is still there on request
     gcall = F._prepare_gae(cu(gam), 0.9, cu(v), cu(nv), cu(r), dd, tt, time_dim)

@@ -24,15 +24,14 @@ def test_library_exports_every_declared_symbol():
     assert _extension.get_lib().trl_abi_version() == _extension.ABI_VERSION
 
 
-def test_cpu_tensors_fail_loudly():
+def test_cpu_tensors_take_the_host_entry_points():
+    """CPU tensors run through the library's own host path (trl_*_cpu; parity: tests/test_cpu_path.py); other devices raise."""
     r = torch.randn(3, 8, 1)
     d = torch.zeros(3, 8, 1, dtype=torch.bool)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        F.generalized_advantage_estimate(0.9, 0.9, r, r, r, d)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        F.td_lambda_return_estimate(0.9, 0.9, r, r, d)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        F.vtrace_advantage_estimate(0.9, r, r, r, r, r, d)
+    adv, vt = F.generalized_advantage_estimate(0.9, 0.9, r, r, r, d)
+    assert adv.device.type == "cpu" and adv.shape == r.shape
+    with pytest.raises(RuntimeError, match="HIP .* and CPU tensors"):
+        F.generalized_advantage_estimate(0.9, 0.9, *(t.to("meta") for t in (r, r, r, d)))
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -16,9 +16,15 @@ from torchrl_amd.objectives.value import functional as F  # noqa: E402
 DEV = "cuda:0"
 
 
-def timeit(fn, iters, warm=300):
-    for _ in range(warm):   # clock-settle pre-roll: the first few hundred microseconds of work run at a lower clock
+def timeit(fn, iters, warm=300, settle_s=0.03):
+    # clock-settle pre-roll: a fresh box runs the first milliseconds of work at a lower clock (round 3: 300 launches of a
+    # 5 us kernel were not enough -- C2 read 7.2 us instead of 4.5): at least `warm` calls AND `settle_s` of wall clock
+    import time
+    t_end = time.perf_counter() + settle_s
+    k = 0
+    while k < warm or time.perf_counter() < t_end:
         fn()
+        k += 1
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -83,6 +89,12 @@ def main():
     report("C4 [65536x32] GAE f32", timeit(F.prepare_gae_step(call, normalize=False).run, 4 * it), n, 22)
     report("C4 [65536x32] GAE+normalise f32 (fused)", timeit(F.prepare_gae_step(call, 1e-4, normalize=True).run, 4 * it), n, 22)
     report("C4 [65536x32] GAE+normalise f32 (scan+normalize kernels)", timeit(F.prepare_gae_step(call, 1e-4, normalize=True, algo=F.ALGO_SCAN).run, 4 * it), n, 22)
+    # the per-GPU shards of the strong-scaled batch (BASELINE config 4: [65536 / N x 32] on N GPUs), alone on one GPU
+    for n_gpus in (2, 4, 8):
+        sh = (65536 // n_gpus, 32, 1)
+        rs, vs_, nvs, ds, ts, *_ = inputs(sh, f32, 0.01)
+        cs = F._prepare_gae(0.99, 0.95, vs_, nvs, rs, ds, ts, -2)
+        report(f"C4 shard [{sh[0]}x32] (N = {n_gpus}) GAE+normalise f32 (fused)", timeit(F.prepare_gae_step(cs, 1e-4, normalize=True).run, 4 * it), rs.numel(), 22)
     report("C4 [65536x32] TD(lambda) f32", timeit(lambda: F.td_lambda_return_estimate(0.99, 0.95, nv, r, d, t), 4 * it), n, 14)
     report("C4 [65536x32] V-trace f32", timeit(lambda: F.vtrace_advantage_estimate(0.99, lp, lm, v, nv, r, d, t), 4 * it), n, 30)
     report("C4 [65536x32] GAE f32 SEQ family", timeit(F.prepare_gae_step(call, normalize=False, algo=F.ALGO_SEQ).run, it), n, 22)

@@ -86,6 +86,23 @@ _PROTOTYPES = {
     "trl_gae_normalize_xchg_fwd": (_int, [_vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _dbl,
                                           _i64, _i64, _i64, _vp, _vp, _dbl, _vp, _vp, _sz, _vp, _int]),
     "trl_xchg_destroy": (_int, [_vp, _vp]),
+    # host entry points (tensors in host memory)
+    "trl_cpu_threads": (_int, []),
+    "trl_set_cpu_threads": (_int, [_int]),
+    "trl_gae_fwd_cpu": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "trl_gae_normalize_fwd_cpu": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _i64, _vp, _vp,
+                                         _dbl, _vp]),
+    "trl_td_lambda_fwd_cpu": (_int, [_int, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _int, _i64, _i64, _i64, _vp]),
+    "trl_td1_fwd_cpu": (_int, [_int, _int, _vp, _vp, _vp, _vp, _int, _vp, _dbl, _int, _i64, _i64, _i64, _vp]),
+    "trl_vtrace_fwd_cpu": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _dbl, _dbl, _dbl, _vp, _vp,
+                                  _i64, _i64, _i64, _vp, _vp]),
+    "trl_gae_bwd_cpu": (_int, [_int, _int, _vp, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _dbl, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "trl_td_lambda_bwd_cpu": (_int, [_int, _int, _vp, _vp, _vp, _int, _vp, _vp, _dbl, _dbl, _i64, _i64, _i64, _vp, _vp]),
+    "trl_td1_bwd_cpu": (_int, [_int, _int, _vp, _vp, _vp, _int, _vp, _dbl, _i64, _i64, _i64, _vp, _vp]),
+    "trl_vtrace_bwd_cpu": (_int, [_int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _vp, _dbl, _dbl, _dbl, _vp, _vp,
+                                  _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "trl_moments_cpu": (_int, [_int, _vp, _i64, _vp]),
+    "trl_normalize_cpu": (_int, [_int, _vp, _i64, _vp, _dbl, _vp]),
 }
 
 

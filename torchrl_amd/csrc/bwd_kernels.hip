@@ -18,6 +18,7 @@
 // SCAN family: I == 1, any T (short / long / look-back geometries).  SEQ family: any shape, one lane per (o, i) row
 // walking time forwards.
 #include "scan_impl.h"
+#include "seq_rows.h"
 
 namespace {
 
@@ -321,130 +322,29 @@ struct VtraceBwdOp {
 // ---- SEQ family: one lane per (o, i) row, time walked forwards; any shape ----------------------------------------------
 constexpr int kBwdSeqThreads = 64;
 
+// the per-row loops: seq_rows.h (shared with the host entry points of cpu_host.hip)
 template <typename TS, typename TG>
 __global__ __launch_bounds__(kBwdSeqThreads) void gae_bwd_seq_kernel(GaeBwdArgs a) {
-    using TC = typename Promote<TS, TG>::type;
-    const TS *__restrict__ ga = (const TS *)a.g_adv;
-    const TS *__restrict__ gvt = (const TS *)a.g_vt;
-    const TG *__restrict__ gt = (const TG *)a.gamma_t;
-    const TG *__restrict__ lgt = (const TG *)a.lg_t;
-    TS *__restrict__ dr = (TS *)a.d_reward;
-    TS *__restrict__ dv = (TS *)a.d_value;
-    TS *__restrict__ dnv = (TS *)a.d_next_value;
-    const TG gs = (TG)a.gamma, ls = (TG)a.lmbda, lgs = (TG)a.lg;
     const i64 idx = (i64)blockIdx.x * kBwdSeqThreads + threadIdx.x;
     if (idx >= a.O * a.I) return;
-    const i64 o = idx / a.I, i = idx - o * a.I;
-    i64 j = o * a.T * a.I + i;
-    const i64 ms = a.mask_bcast ? 1 : a.I;
-    i64 mj = a.mask_bcast ? o * a.T : j;
-    TC y = (TC)0;  // a_{t-1} G_{t-1}
-    for (i64 t = 0; t < a.T; ++t, j += a.I, mj += ms) {
-        const TG g = gt ? gt[j] : gs;
-        const TG c = lgt ? lgt[j] : (gt ? ls * g : lgs);
-        const TS gv = gvt ? gvt[j] : (TS)0;
-        const TC G = ((ga ? (TC)ga[j] : (TC)0) + (TC)gv) + y;
-        if (dr) dr[j] = (TS)G;
-        if (dv) dv[j] = (TS)((TC)gv - G);
-        if (dnv) dnv[j] = (TS)(G * (TC)(g * (TG)(a.terminated[mj] ? 0 : 1)));
-        y = (TC)(c * (TG)(a.done[mj] ? 0 : 1)) * G;
-    }
+    const i64 o = idx / a.I;
+    seqrow::gae_bwd_row<TS, TG>(a, o, idx - o * a.I);
 }
 
 template <typename TS, typename TG, bool TD1>
 __global__ __launch_bounds__(kBwdSeqThreads) void td_bwd_seq_kernel(TdBwdArgs a) {
-    using TC = typename Promote<TS, TG>::type;
-    const TS *__restrict__ gr = (const TS *)a.g_ret;
-    const TG *__restrict__ gt = (const TG *)a.gamma_t;
-    const TG *__restrict__ lt = (const TG *)a.lmbda_t;
-    TS *__restrict__ dr = (TS *)a.d_reward;
-    TS *__restrict__ dnv = (TS *)a.d_next_value;
     const i64 idx = (i64)blockIdx.x * kBwdSeqThreads + threadIdx.x;
     if (idx >= a.O * a.I) return;
-    const i64 o = idx / a.I, i = idx - o * a.I;
-    i64 j = o * a.T * a.I + i;
-    const i64 ms = a.mask_bcast ? 1 : a.I;
-    i64 mj = a.mask_bcast ? o * a.T : j;
-    TC y = (TC)0;
-    for (i64 t = 0; t < a.T; ++t, j += a.I, mj += ms) {
-        const TG ge = gt ? gt[j] : (TG)a.gamma;
-        const bool tmv = a.terminated[mj] != 0, dv_ = a.done[mj] != 0;
-        const TC nt = (TC)(tmv ? 0 : 1), dn = (TC)(dv_ ? 1 : 0);
-        TC c, k, tailm;
-        if (TD1) {
-            const TC gnt = (TC)(ge * (TG)(tmv ? 0 : 1));
-            const bool b = dv_ && !tmv;
-            c = gnt * (TC)(b ? 0 : 1);
-            k = gnt * (TC)(b ? 1 : 0);
-            tailm = (TC)1;
-        } else {
-            const TG le = lt ? lt[j] : (TG)a.lmbda;
-            c = ((TC)ge * (TC)le) * ((TC)1 - dn);
-            k = ((TC)ge * (((TC)1 - (TC)le) + (TC)le * dn)) * nt;
-            tailm = nt;
-        }
-        const TC G = (TC)gr[j] + y;
-        y = c * G;
-        TC d = G * k;
-        if (t == a.T - 1) d = d + y * tailm;
-        if (dr) dr[j] = (TS)G;
-        if (dnv) dnv[j] = (TS)d;
-    }
+    const i64 o = idx / a.I;
+    seqrow::td_bwd_row<TS, TG, TD1>(a, o, idx - o * a.I);
 }
 
 template <typename TS, typename TG>
 __global__ __launch_bounds__(kBwdSeqThreads) void vtrace_bwd_seq_kernel(VtraceBwdArgs a) {
-    using TC = typename Promote<TS, TG>::type;
-    const TC *__restrict__ ga = (const TC *)a.g_adv;
-    const TC *__restrict__ gs = (const TC *)a.g_vs;
-    const TC *__restrict__ vs = (const TC *)a.vs;
-    const TS *__restrict__ lp = (const TS *)a.log_pi;
-    const TS *__restrict__ lmu = (const TS *)a.log_mu;
-    const TS *__restrict__ v = (const TS *)a.value;
-    const TS *__restrict__ nv = (const TS *)a.next_value;
-    const TS *__restrict__ r = (const TS *)a.reward;
-    const TG *__restrict__ gt = (const TG *)a.gamma_t;
-    const TS rho_s = (TS)a.rho_thresh, c_s = (TS)a.c_thresh;
-    const TS *__restrict__ rho_t = (const TS *)a.rho_t;
-    const TS *__restrict__ c_t = (const TS *)a.c_t;
     const i64 idx = (i64)blockIdx.x * kBwdSeqThreads + threadIdx.x;
     if (idx >= a.O * a.I) return;
-    const i64 o = idx / a.I, i = idx - o * a.I;
-    i64 j = o * a.T * a.I + i;
-    const i64 ms = a.mask_bcast ? 1 : a.I;
-    i64 mj = a.mask_bcast ? o * a.T : j;
-    TC y = (TC)0, dprev = (TC)0;
-    for (i64 t = 0; t < a.T; ++t, j += a.I, mj += ms) {
-        const bool last_t = t == a.T - 1;
-        const TG ge = gt ? gt[j] : (TG)a.gamma;
-        const TC nd = (TC)(a.done[mj] ? 0 : 1), nt = (TC)(a.terminated[mj] ? 0 : 1);
-        const TG gnd = ge * (TG)(a.done[mj] ? 0 : 1), gnt = ge * (TG)(a.terminated[mj] ? 0 : 1);
-        const TS rho = exp_t(lp[j] - lmu[j]);
-        const TS rho_hi = rho_t ? rho_t[j] : rho_s, c_hi = c_t ? c_t[j] : c_s;
-        const TS rb = clamp_max_nan(rho, rho_hi), cb = clamp_max_nan(rho, c_hi);
-        const TC A = ga ? ga[j] : (TC)0, S = gs ? gs[j] : (TC)0;
-        const TC dvsp = A * (TC)rb * (TC)gnt;
-        const TC coef = (TC)gnd * (TC)cb;
-        const TC X = S + y, st = S + dprev;
-        const TC vs_n = last_t ? (TC)0 : vs[j + a.I];
-        const TC vsp = last_t ? (TC)nv[j] : vs_n;
-        const TC x_next = last_t ? (TC)0 : vs_n - (TC)v[j + a.I];
-        const TC d_rb = A * (((TC)r[j] + (TC)gnt * vsp) - (TC)v[j]) + X * (((TC)r[j] + (TC)gnt * (TC)nv[j]) - (TC)v[j]);
-        const TC d_cb = X * x_next * (TC)gnd;
-        const TC d_rho = (rho <= rho_hi ? d_rb : (TC)0) + (rho <= c_hi ? d_cb : (TC)0);
-        const TC d_lp = d_rho * (TC)rho;
-        const TC w = (A + X) * (TC)rb;
-        TC d_nv = X * (TC)rb * (TC)gnt;
-        if (last_t) d_nv = d_nv + dvsp;
-        if (a.d_log_pi) ((TS *)a.d_log_pi)[j] = (TS)d_lp;
-        if (a.d_log_mu) ((TS *)a.d_log_mu)[j] = (TS)(-d_lp);
-        if (a.d_value) ((TS *)a.d_value)[j] = (TS)(st - w);
-        if (a.d_next_value) ((TS *)a.d_next_value)[j] = (TS)d_nv;
-        if (a.d_reward) ((TS *)a.d_reward)[j] = (TS)w;
-        if (a.d_gamma_t) ((TC *)a.d_gamma_t)[j] = nt * (TC)rb * (A * vsp + X * (TC)nv[j]) + nd * X * x_next * (TC)cb;
-        y = dvsp + coef * X;
-        dprev = dvsp;
-    }
+    const i64 o = idx / a.I;
+    seqrow::vtrace_bwd_row<TS, TG>(a, o, idx - o * a.I);
 }
 
 template <typename F>

@@ -3,6 +3,7 @@
 // (torchrl/objectives/value/functional.py:172-178) and parity at done boundaries is bit-exact.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 typedef unsigned char u8;
@@ -79,7 +80,7 @@ __device__ __forceinline__ void block_sum2(double &s, double &ss, double *smem /
 // mean / clamped std in the storage dtype from {N, sum, sumsq}: what
 // `x.mean()` / `x.std().clamp_min(eps)` give (unbiased std; advantages.py:1459-1463).
 template <typename TS>
-__device__ __forceinline__ void mean_std(double n, double s, double ss, double eps, TS &mean_s, TS &std_s) {
+__host__ __device__ __forceinline__ void mean_std(double n, double s, double ss, double eps, TS &mean_s, TS &std_s) {
     const double mean = s / n;
     double var = (ss - n * mean * mean) / (n - 1.0);  // unbiased, as torch.std
     if (var < 0.0) var = 0.0;                         // rounding only; NaN (n == 1) stays NaN

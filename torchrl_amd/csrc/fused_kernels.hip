@@ -128,7 +128,10 @@ __global__ __launch_bounds__(kFusedThreads) void gae_fused_kernel(typename Op::A
     int nvalid_k[K];
 
     auto geom_of = [&](int k, i64 &start, int &count) {
-        const i64 c = ((i64)k * gridDim.x + blockIdx.x) * kTeams + team;
+        // FULL: a block's four teams take four consecutive chunks (one 16 KB run per tensor and round).  Otherwise consecutive
+        // chunks go to different BLOCKS first, so that a batch of fewer chunks than team slots -- a [65536 / N x 32] shard of
+        // the batch on N GPUs: 256 chunks at N = 8 -- still loads through every CU instead of through the first #chunks / 4
+        const i64 c = FULL ? ((i64)k * gridDim.x + blockIdx.x) * kTeams + team : ((i64)k * kTeams + team) * gridDim.x + blockIdx.x;
         if constexpr (FULL) {
             start = c * (i64)(kTeam * V);
             count = kTeam * V;
@@ -337,7 +340,7 @@ LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *w
                     aligned16(a.value_target);
     const bool vec = al && (nchunks == 1 || (R * a.T) % V == 0);
     const bool wi = ((i64)kWave * V) % a.T == 0;
-    const int KK = k_needed <= 2 ? 2 : k_needed <= 4 ? 4 : 8;
+    const int KK = k_needed <= 1 ? 1 : k_needed <= 2 ? 2 : k_needed <= 4 ? 4 : 8;
     // every team's KK chunks complete: whole chunks (R*T == 256*V), all rows used, exactly KK chunks per team
     const bool full = vec && R * a.T == chunk && a.O % R == 0 && nchunks == (i64)KK * per_iter;
     FusedGeom geo{a.O, a.T, (int)R, scan_lanes_for(a.T, V, wi), nchunks, (double)a.O * (double)a.T, eps, host_flag};
@@ -349,7 +352,8 @@ LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *w
 #define TRL_FUSED_X(VEC, WI, KK_, FULL_) do { if (x) TRL_FUSED(VEC, WI, KK_, FULL_, true); else TRL_FUSED(VEC, WI, KK_, FULL_, false); } while (0)
 #define TRL_FUSED_K(VEC, WI, FULL_)                                        \
     do {                                                                   \
-        if (KK == 2) TRL_FUSED_X(VEC, WI, 2, FULL_);                       \
+        if (KK == 1) TRL_FUSED_X(VEC, WI, 1, FULL_);                       \
+        else if (KK == 2) TRL_FUSED_X(VEC, WI, 2, FULL_);                  \
         else if (KK == 4) TRL_FUSED_X(VEC, WI, 4, FULL_);                  \
         else if constexpr (!kMixed) TRL_FUSED_X(VEC, WI, 8, FULL_);        \
     } while (0)

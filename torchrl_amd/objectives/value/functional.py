@@ -4,8 +4,10 @@ Drop-in for ``torchrl.objectives.value.functional`` (reference:
 torchrl/objectives/value/functional.py): same names, argument order, keyword-only
 ``time_dim`` where the reference has it, same ``done`` / ``terminated`` semantics, same
 ``[*B, T, *F]`` conventions and the same exceptions.  Everything below the Python signature
-is replaced by one call into the HIP library (include/trl_value.h); there is no PyTorch or
-CPU fallback -- a CPU tensor or a missing library raises.
+is replaced by one call into the native library (include/trl_value.h): the gfx950 kernels for tensors on the GPU,
+the library's own host entry points (``trl_*_cpu``: the SEQ family's row functions run by a few threads) for tensors
+in host memory -- the reference, too, runs on whatever device its tensors live on (functional.py:163-170).  There is
+no PyTorch fallback and the test oracle is never involved: a missing library raises.
 
 Host-side work done here (and only here):
   * shape / time-dim validation with the reference's error types and messages
@@ -152,9 +154,20 @@ def _check_value_dtype(*tensors) -> torch.dtype:
 def _require_hip(t: torch.Tensor):
     if t.device.type != "cuda":
         raise RuntimeError(
-            "torchrl_amd value estimators run on MI355X (HIP, device type 'cuda') tensors only; "
-            f"got a tensor on {t.device}. There is no CPU fallback."
+            "this torchrl_amd entry point (prepared steps, cross-GPU exchange, workspaces) runs on MI355X (HIP, device type "
+            f"'cuda') tensors only; got a tensor on {t.device}."
         )
+
+
+def _on_host(t: torch.Tensor) -> bool:
+    """True for tensors in host memory (the library's ``trl_*_cpu`` entry points take them); HIP tensors give False, any
+    other device raises."""
+    kind = t.device.type
+    if kind == "cpu":
+        return True
+    if kind != "cuda":
+        raise RuntimeError(f"torchrl_amd value estimators run on HIP (device type 'cuda') and CPU tensors; got a tensor on {t.device}")
+    return False
 
 
 def _val(t: torch.Tensor, dtype, device=None) -> torch.Tensor:
@@ -382,7 +395,7 @@ def _lookback_workspace(lib, dev, O, T, I):
 
 def _launch_gae(c: _GaeCall, want_stats: bool = False, algo: int = ALGO_AUTO, out=None):
     lib = _extension.get_lib()
-    _require_hip(c.reward)
+    host = _on_host(c.reward)
     dev = c.reward.device
     adv, vt = out if out is not None else (torch.empty(c.shape, dtype=c.vdt, device=dev), torch.empty(c.shape, dtype=c.vdt, device=dev))
     stats = ws = None
@@ -390,6 +403,15 @@ def _launch_gae(c: _GaeCall, want_stats: bool = False, algo: int = ALGO_AUTO, ou
     if c.O * c.T * c.I == 0:  # nothing to scan (the reference's loop runs zero steps): empty outputs, zero moments
         stats = torch.zeros(3, dtype=torch.float64, device=dev) if want_stats else None
         return adv.to(c.out_dtype), vt.to(c.out_dtype), stats
+    if host:  # tensors in host memory: the library's row-sequential host path (one family; `algo` does not apply)
+        stats = torch.empty(3, dtype=torch.float64) if want_stats else None
+        rc = lib.trl_gae_fwd_cpu(_DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.value), _ptr(c.next_value), _ptr(c.done),
+                                 _ptr(c.terminated), c.mask_bcast, _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg,
+                                 c.O, c.T, c.I, _ptr(adv), _ptr(vt), _ptr(stats))
+        _extension.check(rc, lib)
+        if c.out_dtype != c.vdt:
+            adv, vt = adv.to(c.out_dtype), vt.to(c.out_dtype)
+        return adv, vt, stats
     if want_stats:
         ws = _workspace(lib, dev, c.O, c.T, c.I)
         stats = torch.empty(3, dtype=torch.float64, device=dev)
@@ -412,13 +434,24 @@ def _launch_gae_normalize(c: _GaeCall, eps: float, algo: int = ALGO_AUTO, out=No
     ``exchange`` (:class:`StatsExchange`): the batch is sharded over its ranks; the moments are
     summed across GPUs inside the launch (trl_gae_normalize_xchg_fwd)."""
     lib = _extension.get_lib()
-    _require_hip(c.reward)
+    host = _on_host(c.reward)
     dev = c.reward.device
     adv, vt = out if out is not None else (torch.empty(c.shape, dtype=c.vdt, device=dev), torch.empty(c.shape, dtype=c.vdt, device=dev))
     if c.O * c.T * c.I == 0:
         if exchange is not None:
             raise NotImplementedError("gae_normalized: an empty shard cannot take part in the cross-GPU exchange")
         return adv.to(c.out_dtype), vt.to(c.out_dtype), (torch.zeros(3, dtype=torch.float64, device=dev) if want_stats else None)
+    if host:
+        if exchange is not None:
+            _require_hip(c.reward)
+        stats = torch.empty(3, dtype=torch.float64) if want_stats else None
+        rc = lib.trl_gae_normalize_fwd_cpu(_DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.value), _ptr(c.next_value), _ptr(c.done),
+                                           _ptr(c.terminated), c.mask_bcast, _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg,
+                                           c.O, c.T, c.I, _ptr(adv), _ptr(vt), float(eps), _ptr(stats))
+        _extension.check(rc, lib)
+        if c.out_dtype != c.vdt:
+            adv, vt = adv.to(c.out_dtype), vt.to(c.out_dtype)
+        return adv, vt, stats
     ws = _workspace(lib, dev, c.O, c.T, c.I)
     stats = torch.empty(3, dtype=torch.float64, device=dev) if want_stats else None
     head = (_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.value), _ptr(c.next_value),
@@ -455,10 +488,10 @@ def last_bwd_kernel() -> str:
     return _LAST_BWD_KERNEL
 
 
-def _bwd_done(rc, lib):
+def _bwd_done(rc, lib, name=None):
     global _LAST_BWD_KERNEL
     _extension.check(rc, lib)
-    _LAST_BWD_KERNEL = lib.trl_last_kernel().decode()
+    _LAST_BWD_KERNEL = name or lib.trl_last_kernel().decode()
 
 
 def _grad_in(g, c, dt):
@@ -518,7 +551,11 @@ def _gae_bwd(c, g_adv, g_vt, need_v: bool, need_nv: bool, need_r: bool):
     ga, gv = _grad_in(g_adv, c, c.vdt), _grad_in(g_vt, c, c.vdt)
     new = lambda on: torch.empty(c.shape, dtype=c.vdt, device=dev) if on else None
     d_v, d_nv, d_r = new(need_v), new(need_nv), new(need_r)
-    if d_v is not None or d_nv is not None or d_r is not None:
+    if (d_v is not None or d_nv is not None or d_r is not None) and _on_host(c.reward):
+        rc = lib.trl_gae_bwd_cpu(_DT[c.vdt], _DT[c.cdt], _ptr(ga), _ptr(gv), _ptr(c.done), _ptr(c.terminated), c.mask_bcast,
+                                 _ptr(c.gamma_t), _ptr(c.lg_t), c.gamma, c.lmbda, c.lg, c.O, c.T, c.I, _ptr(d_r), _ptr(d_v), _ptr(d_nv))
+        _bwd_done(rc, lib, "gae_bwd_cpu")
+    elif d_v is not None or d_nv is not None or d_r is not None:
         wsp, wsb, _ws = _bwd_ws(lib, c)
         with _on(dev):
             rc = lib.trl_gae_bwd(_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(ga), _ptr(gv), _ptr(c.done), _ptr(c.terminated),
@@ -585,6 +622,15 @@ def _td_bwd(c, g_ret, td1: bool, need_nv: bool, need_r: bool):
     gr = _grad_in(g_ret, c, c.vdt)
     d_nv = torch.empty(c.shape, dtype=c.vdt, device=dev) if need_nv else None
     d_r = torch.empty(c.shape, dtype=c.vdt, device=dev) if need_r else None
+    if _on_host(c.reward):
+        if td1:
+            rc = lib.trl_td1_bwd_cpu(_DT[c.vdt], _DT[c.cdt], _ptr(gr), _ptr(c.done), _ptr(c.terminated), c.mask_bcast, _ptr(c.gamma_t),
+                                     c.gamma, c.O, c.T, c.I, _ptr(d_r), _ptr(d_nv))
+        else:
+            rc = lib.trl_td_lambda_bwd_cpu(_DT[c.vdt], _DT[c.cdt], _ptr(gr), _ptr(c.done), _ptr(c.terminated), c.mask_bcast,
+                                           _ptr(c.gamma_t), _ptr(c.lmbda_t), c.gamma, c.lmbda, c.O, c.T, c.I, _ptr(d_r), _ptr(d_nv))
+        _bwd_done(rc, lib, "td1_bwd_cpu" if td1 else "td_lambda_bwd_cpu")
+        return d_nv, d_r
     wsp, wsb, _ws = _bwd_ws(lib, c)
     with _on(dev):
         if td1:
@@ -603,6 +649,9 @@ def _td_fixed_bwd(c, g_ret, td1: bool, need_nv: bool, need_r: bool, need_gamma: 
     dtype and the per-element ``(d_gamma, d_lmbda)`` in the compute dtype (None where not needed)."""
     lib = _extension.get_lib()
     dev = c.reward.device
+    if _on_host(c.reward):
+        raise NotImplementedError("torchrl_amd: the backward of rolling_gamma=False runs on the GPU only (trl_td_fixed_bwd has no host "
+                                  "counterpart); move the tensors to the HIP device or call under torch.no_grad()")
     gr = _grad_in(g_ret, c, c.vdt)
     cdt = torch.promote_types(c.vdt, c.cdt)
     new = lambda on, dt: torch.empty(c.shape, dtype=dt, device=dev) if on else None
@@ -726,6 +775,13 @@ def _vtrace_bwd(c, g_adv, g_vs, vs, need, need_gamma: bool):
     if vs.dtype != odt:
         vs = vs.to(odt)
     vs = vs.contiguous()
+    if _on_host(c.reward):
+        rc = lib.trl_vtrace_bwd_cpu(_DT[c.vdt], _DT[c.cdt], _ptr(ga), _ptr(gs), _ptr(c.log_pi), _ptr(c.log_mu), _ptr(c.value),
+                                    _ptr(c.next_value), _ptr(c.reward), _ptr(vs), _ptr(c.done), _ptr(c.terminated), c.mask_bcast,
+                                    _ptr(c.gamma_t), c.gamma, c.rho_thresh, c.c_thresh, _ptr(c.rho_t), _ptr(c.c_t), c.O, c.T, c.I,
+                                    *(_ptr(o) for o in outs), _ptr(d_gamma_t))
+        _bwd_done(rc, lib, "vtrace_bwd_cpu")
+        return outs, d_gamma_t
     wsp, wsb, _ws = _bwd_ws(lib, c)
     with _on(dev):
         rc = lib.trl_vtrace_bwd(_stream(dev), _DT[c.vdt], _DT[c.cdt], _ptr(ga), _ptr(gs), _ptr(c.log_pi), _ptr(c.log_mu),
@@ -1126,11 +1182,14 @@ def gae_normalized(gamma, lmbda, state_value, next_state_value, reward, done, te
 def moments(x: torch.Tensor) -> torch.Tensor:
     """``{N, sum, sumsq}`` of ``x`` in fp64 (device tensor of 3 doubles)."""
     lib = _extension.get_lib()
-    _require_hip(x)
     xc = x.detach().contiguous()
     if xc.dtype not in _DT:
         raise NotImplementedError(f"moments: dtype {xc.dtype} unsupported")
     n = xc.numel()
+    if _on_host(x):
+        stats = torch.empty(3, dtype=torch.float64)
+        _extension.check(lib.trl_moments_cpu(_DT[xc.dtype], _ptr(xc), n, _ptr(stats)), lib)
+        return stats
     ws = _workspace(lib, x.device, n, 1, 1)
     stats = torch.empty(3, dtype=torch.float64, device=x.device)
     with _on(x.device):
@@ -1143,7 +1202,6 @@ def normalize_(x: torch.Tensor, stats: torch.Tensor, eps: float, out: Optional[t
     """``(x - mean) / std.clamp_min(eps)`` with mean / unbiased std taken from ``stats``
     (reference: advantages.py:1459-1463).  In place unless ``out`` is given."""
     lib = _extension.get_lib()
-    _require_hip(x)
     if not x.is_contiguous() or x.dtype not in _DT:
         raise ValueError("normalize_: x must be a contiguous float32/float64 tensor")
     if stats.dtype != torch.float64 or stats.numel() != 3 or stats.device != x.device:
@@ -1151,6 +1209,9 @@ def normalize_(x: torch.Tensor, stats: torch.Tensor, eps: float, out: Optional[t
     out = x if out is None else out
     if out.shape != x.shape or out.dtype != x.dtype or not out.is_contiguous():
         raise ValueError("normalize_: out must match x")
+    if _on_host(x):
+        _extension.check(lib.trl_normalize_cpu(_DT[x.dtype], _ptr(x), x.numel(), _ptr(stats), float(eps), _ptr(out)), lib)
+        return out
     with _on(x.device):
         rc = lib.trl_normalize(_stream(x.device), _DT[x.dtype], _ptr(x), x.numel(), _ptr(stats), float(eps), _ptr(out))
     _extension.check(rc, lib)
@@ -1191,13 +1252,14 @@ def standardize(x: torch.Tensor, eps: float, group=None, distributed: bool = Fal
         return normalize_(xc, st, eps, out=torch.empty_like(xc))
     # single GPU: one C-ABI call (one single-block launch up to 65536 elements -- a PPO minibatch)
     lib = _extension.get_lib()
-    _require_hip(xc)
     if xc.dtype not in _DT:
         raise NotImplementedError(f"standardize: dtype {xc.dtype} unsupported")
     n = xc.numel()
     out = torch.empty_like(xc)
     if n == 0:
         return out
+    if _on_host(xc):
+        return normalize_(xc, moments(xc), eps, out=out)
     dev = xc.device
     ws = _workspace(lib, dev, n, 1, 1) if n > 65536 else None
     with _on(dev):
@@ -1281,11 +1343,16 @@ def _prepare_td_lambda(gamma, lmbda, next_state_value, reward, done, terminated,
 
 def _launch_td_lambda(c: _TdLambdaCall, out_dtype, algo: int = ALGO_AUTO) -> torch.Tensor:
     lib = _extension.get_lib()
-    _require_hip(c.reward)
     dev = c.reward.device
     out = torch.empty(c.shape, dtype=c.vdt, device=dev)
     if c.O * c.T * c.I == 0:
         return out.to(out_dtype)
+    if _on_host(c.reward):
+        rc = lib.trl_td_lambda_fwd_cpu(_DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.next_value), _ptr(c.done), _ptr(c.terminated),
+                                       c.mask_bcast, _ptr(c.gamma_t), _ptr(c.lmbda_t), c.gamma, c.lmbda, 1 if c.rolling else 0,
+                                       c.O, c.T, c.I, _ptr(out))
+        _extension.check(rc, lib)
+        return out if out_dtype == c.vdt else out.to(out_dtype)
     ws = _lookback_workspace(lib, dev, c.O, c.T, c.I) if c.rolling else None
     with _on(dev):
         rc = lib.trl_td_lambda_fwd(
@@ -1519,12 +1586,17 @@ def _prepare_vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward
 
 def _launch_vtrace(c: _VtraceCall, algo: int = ALGO_AUTO):
     lib = _extension.get_lib()
-    _require_hip(c.reward)
     dev = c.reward.device
     odt = torch.promote_types(c.vdt, c.cdt)
     adv = torch.empty(c.shape, dtype=odt, device=dev)
     vs = torch.empty(c.shape, dtype=odt, device=dev)
     if c.O * c.T * c.I == 0:
+        return adv, vs
+    if _on_host(c.reward):
+        rc = lib.trl_vtrace_fwd_cpu(_DT[c.vdt], _DT[c.cdt], _ptr(c.log_pi), _ptr(c.log_mu), _ptr(c.value), _ptr(c.next_value),
+                                    _ptr(c.reward), _ptr(c.done), _ptr(c.terminated), c.mask_bcast, _ptr(c.gamma_t), c.gamma,
+                                    c.rho_thresh, c.c_thresh, _ptr(c.rho_t), _ptr(c.c_t), c.O, c.T, c.I, _ptr(adv), _ptr(vs))
+        _extension.check(rc, lib)
         return adv, vs
     ws = _lookback_workspace(lib, dev, c.O, c.T, c.I)
     with _on(dev):
@@ -1654,11 +1726,15 @@ def _prepare_td1(gamma, next_state_value, reward, done, terminated, rolling_gamm
 
 def _launch_td1(c: _TdLambdaCall, out_dtype, algo: int = ALGO_AUTO) -> torch.Tensor:
     lib = _extension.get_lib()
-    _require_hip(c.reward)
     dev = c.reward.device
     out = torch.empty(c.shape, dtype=c.vdt, device=dev)
     if c.O * c.T * c.I == 0:
         return out.to(out_dtype)
+    if _on_host(c.reward):
+        rc = lib.trl_td1_fwd_cpu(_DT[c.vdt], _DT[c.cdt], _ptr(c.reward), _ptr(c.next_value), _ptr(c.done), _ptr(c.terminated),
+                                 c.mask_bcast, _ptr(c.gamma_t), c.gamma, 1 if c.rolling else 0, c.O, c.T, c.I, _ptr(out))
+        _extension.check(rc, lib)
+        return out if out_dtype == c.vdt else out.to(out_dtype)
     ws = _lookback_workspace(lib, dev, c.O, c.T, c.I) if c.rolling else None
     with _on(dev):
         rc = lib.trl_td1_fwd(
