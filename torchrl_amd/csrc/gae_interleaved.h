@@ -39,12 +39,10 @@ struct GaePreparedOp {  // what scan_chunk needs of an estimator whose per-step 
 // A variant with every row in its own aligned power-of-two lane group (no row crosses a wave: no cross-wave stage, no
 // hard-reset flag; 5- or 8-wave blocks, 25 of 32 lanes busy in the row phase) was built and measured: 11.4 - 15.7 us at C3
 // against 9.5 -- the idle lanes and the fewer resident chunks cost more than the stage it removes.  Dropped.
-#ifndef GIL_WAVES
-#define GIL_WAVES 4
-#endif
+constexpr int kGilBlocksPerCu = 4;  // resident blocks per CU = the grid's blocks per CU (measured above)
 
 template <typename TS, typename TG, int V, bool VEC, bool WAVE_INDEP, bool PAD>
-__global__ __launch_bounds__(kTeam, GIL_WAVES) void gae_interleaved_kernel(GaeArgs args, ScanGeom geo, int I, double *partials) {
+__global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel(GaeArgs args, ScanGeom geo, int I, double *partials) {
     typedef typename Promote<TS, TG>::type TC;
     typedef GaePreparedOp<TS, TC, V> Op;
     constexpr int CH = kTeam * V;
@@ -122,14 +120,10 @@ __global__ __launch_bounds__(kTeam, GIL_WAVES) void gae_interleaved_kernel(GaeAr
 
     double s = 0.0, ss = 0.0;
     const i64 niter = (geo.nchunks + gridDim.x - 1) / gridDim.x;
-#ifndef GIL_PREFETCH
-#define GIL_PREFETCH 1
-#endif
     Raw cur, nxt;
-    if (GIL_PREFETCH) load_raw(0, cur);
+    load_raw(0, cur);
     for (i64 it = 0; it < niter; ++it) {
-        if (GIL_PREFETCH) { if (it + 1 < niter) load_raw(it + 1, nxt); }  // the next chunk's loads fly while this one goes through LDS
-        else load_raw(it, cur);
+        if (it + 1 < niter) load_raw(it + 1, nxt);  // the next chunk's loads fly while this one goes through LDS
         i64 row0, start;
         int count;
         geom_of(it, row0, start, count);
@@ -191,15 +185,10 @@ __global__ __launch_bounds__(kTeam, GIL_WAVES) void gae_interleaved_kernel(GaeAr
                 adv[e] = src[e];
                 vt[e] = adv[e] + v[e];
             }
-#ifdef GIL_WT
-            store_wt<VEC>((TS *)args.advantage, flat, nvalid, adv);
-            store_wt<VEC>((TS *)args.value_target, flat, nvalid, vt);
-#else
             store_n<VEC>((TS *)args.advantage, flat, nvalid, adv);
             store_n<VEC>((TS *)args.value_target, flat, nvalid, vt);
-#endif
         }
-        if (GIL_PREFETCH) cur = nxt;
+        cur = nxt;
     }
     if (partials) {
         block_sum2<kTeam>(s, ss, red);
@@ -214,10 +203,7 @@ template <typename TS, typename TG, int V>
 LaunchResult launch_gae_interleaved(hipStream_t s, const GaeArgs &a, const Plan &p, int cus) {
     ScanGeom geo{a.O, a.T, p.rows_per_chunk, scan_lanes_for(a.T, V, p.wave_indep), p.nchunks};
     i64 nb = p.nchunks;
-#ifndef GIL_BPC
-#define GIL_BPC 4
-#endif
-    if (nb > (i64)cus * GIL_BPC) nb = (i64)cus * GIL_BPC;
+    if (nb > (i64)cus * kGilBlocksPerCu) nb = (i64)cus * kGilBlocksPerCu;
     if (nb > 4096) nb = 4096;  // per-block partials: scan_max_partials
     typedef typename Promote<TS, TG>::type TC;
     const i64 stride_words = (i64)V * a.I * (i64)(sizeof(TC) / 4);

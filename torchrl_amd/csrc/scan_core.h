@@ -68,11 +68,7 @@ template <typename T, int V>
 __device__ __forceinline__ void vload(const T *__restrict__ p, T (&out)[V]) {
     constexpr int B = V * (int)sizeof(T);
     if constexpr (B <= 16) {
-#ifdef TRL_NT_LOADS  // development switch (tools/kbench): non-temporal input loads
-        typename RawT<B>::type raw = __builtin_nontemporal_load((const typename RawT<B>::type *)p);
-#else
         typename RawT<B>::type raw = *(const typename RawT<B>::type *)p;
-#endif
         __builtin_memcpy(out, &raw, B);
     } else {
         static_assert(B % 16 == 0, "vector width");
@@ -700,19 +696,11 @@ __device__ __forceinline__ void scan_chunk_t(const Op &op, TeamShared<Op> &sh, i
         // The sources are three fixed lanes: v_readlane + select instead of ds_bpermute shuffles (same values, same
         // composition order; ~2 x 120 cycles less latency per chunk on the chain scan -> carry -> replay).
         const int row = lane >> 4;
-#ifdef TRL_SCAN_SHFL  // development switch: the shuffle form
-        Aff<TC> p = Aff<TC>{__shfl(S.a, (row + 1) << 4, kWave), __shfl(S.b, (row + 1) << 4, kWave),
-                            __shfl(S.h, (row + 1) << 4, kWave)};
-        if ((row & 1) == 0) S = compose_t<HARD>(S, p);
-        p = Aff<TC>{__shfl(S.a, 32, kWave), __shfl(S.b, 32, kWave), __shfl(S.h, 32, kWave)};
-        if (row < 2) S = compose_t<HARD>(S, p);
-#else
         const Aff<TC> p16{read_lane(S.a, 16), read_lane(S.b, 16), HARD ? read_lane(S.h, 16) : 0};
         const Aff<TC> p48{read_lane(S.a, 48), read_lane(S.b, 48), HARD ? read_lane(S.h, 48) : 0};
         if ((row & 1) == 0) S = compose_t<HARD>(S, row == 0 ? p16 : p48);
         const Aff<TC> p32{read_lane(S.a, 32), read_lane(S.b, 32), HARD ? read_lane(S.h, 32) : 0};
         if (row < 2) S = compose_t<HARD>(S, p32);
-#endif
     }
     // exclusive: everything after this lane, within the wave (whole-wave shift by one lane)
     Aff<TC> E{dpp_mov<0x130>(S.a), dpp_mov<0x130>(S.b), HARD ? dpp_mov<0x130>(S.h) : 0};

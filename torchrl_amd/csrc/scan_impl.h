@@ -135,11 +135,8 @@ __global__ __launch_bounds__(kShortThreads) void scan_short_kernel(typename Op::
 // then looks exactly like RO*I time-contiguous rows of length T and goes through the same
 // scan_chunk.  Outputs take the inverse route (LDS scatter, coalesced 16-byte stores), so HBM
 // traffic stays at the algorithmic bytes.
-#ifndef IL_WAVES
-#define IL_WAVES 4
-#endif
 template <class Op, bool VEC, bool WAVE_INDEP, bool PAD>
-__global__ __launch_bounds__(kTeam, IL_WAVES) void scan_interleaved_kernel(typename Op::Args args, ScanGeom geo, int I, double *partials) {
+__global__ __launch_bounds__(kTeam, 4) void scan_interleaved_kernel(typename Op::Args args, ScanGeom geo, int I, double *partials) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
     typedef typename Op::TO TO;
