@@ -173,3 +173,32 @@ def test_noalloc_give_up_is_reported_through_the_static_scratch():
     assert call() == 0
     assert lib.trl_last_kernel().decode() == "gae_fused"
     assert torch.equal(adv, good)
+
+
+def test_one_launch_standardize_gives_up_loudly_and_degrades():
+    """The persistent `_standardize` kernels (ungrouped and per-agent) have the same co-residency requirement and the same
+    failure semantics: un-normalised output, never NaN, one warning on the next call, multi-launch route from then on."""
+    from torchrl_amd._utils import _standardize
+
+    hold_half = _holder()
+    F.fused_reset()
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn((4096, 100, 5, 1), generator=g) * 2 + 3).to(DEV)
+    for ex, kernel, slow in (((-2,), "standardize_grouped_persistent", "normalize_grouped"), ((), "standardize_persistent", "normalize")):
+        want = _standardize(x, ex)
+        assert F.last_kernel() == kernel
+        torch.cuda.synchronize()
+        hold_half()
+        got = _standardize(x, ex)
+        assert F.last_kernel() == kernel
+        torch.cuda.synchronize()
+        assert torch.isfinite(got).all()
+        raw = got == x
+        assert bool((raw | (got == want)).all()) and raw.float().mean() > 0.2
+        with pytest.warns(RuntimeWarning, match="gave up waiting"):
+            again = _standardize(x, ex)
+        assert F.last_kernel() == slow and F.fused_degraded()
+        torch.testing.assert_close(again, want, rtol=3e-6, atol=3e-6)
+        F.fused_reset()
+        assert torch.equal(_standardize(x, ex), want) and F.last_kernel() == kernel
+    _clean_workspaces()

@@ -205,6 +205,71 @@ def test_host_module_and_python_routes_agree(shape, time_dim, masks, dtype, defa
             assert torch.equal(a, b), f"{k}: max abs diff {(a - b).abs().max().item()}"
 
 
+def _coef_forms(shape, dtype, g, l):
+    """gamma / lmbda the ways the reference's tests pass them (test_cost.py:14147-14197) and a few more."""
+    full = lambda x, dt=dtype: torch.full(shape, x, dtype=dt, device=DEV)
+    ramp = lambda x: (x - 0.05 * torch.rand(shape, generator=torch.Generator().manual_seed(3))).to(dtype).to(DEV)
+    other = torch.float64 if dtype == torch.float32 else torch.float32
+    return {
+        "zero_dim_host": (torch.tensor(g, dtype=dtype), torch.tensor(l, dtype=dtype), True),
+        "zero_dim_host_other_dtype": (torch.tensor(g, dtype=other), l, True),
+        "one_element_device": (torch.as_tensor([g], device=DEV, dtype=dtype), torch.as_tensor([l], device=DEV, dtype=dtype), True),
+        "one_element_gamma_float_lmbda": (torch.as_tensor([g], dtype=dtype), l, True),
+        "full_gamma_float_lmbda": (ramp(g), l, True),
+        "full_gamma_one_element_lmbda": (full(g), torch.tensor(l, dtype=dtype), True),
+        "full_both": (ramp(g), ramp(l), True),
+        "float_gamma_full_lmbda": (g, ramp(l), None),         # eligible only when the default dtype is the value dtype
+        "full_gamma_other_dtype": (full(g, other), l, False),  # coefficient dtype != value dtype: python's general path
+    }
+
+
+@pytest.mark.parametrize("default_dtype", [torch.float32, torch.float64], ids=["def32", "def64"], indirect=True)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape,time_dim", [((6, 40, 1), -2), ((9, 20, 3, 1), -3)])
+def test_host_module_takes_tensor_coefficients(shape, time_dim, dtype, default_dtype, monkeypatch):
+    """gamma / lmbda as 0-dim or 1-element tensors (host or device) and as tensors of the inputs' shape go through the C++
+    host module too: same C-ABI call as python's general path -- bit for bit, dtype for dtype -- and the
+    module really takes them (it returns outputs, not None)."""
+    assert F.host_fast_path(), "lib/_trl_host.so is not built (make -C torchrl_amd/csrc)"
+    host = F._HOST
+    g = torch.Generator().manual_seed(12)
+    mk = lambda: torch.randn(shape, generator=g, dtype=torch.float32).to(dtype).to(DEV)
+    r, v, nv = mk(), mk(), mk()
+    lp = torch.rand(shape, generator=g).clamp_min(1e-3).log().to(dtype).to(DEV)
+    lm = torch.rand(shape, generator=g).clamp_min(1e-3).log().to(dtype).to(DEV)
+    term = (torch.rand(shape, generator=g) < 0.05).to(DEV)
+    done = term | (torch.rand(shape, generator=g) < 0.05).to(DEV)
+    forms = _coef_forms(shape, dtype, 0.97, 0.9)
+    fast, taken = {}, {}
+    for name, (gam, lam, _) in forms.items():
+        taken[name] = (
+            host.gae(gam, lam, v, nv, r, done, term, None, F.ALGO_AUTO, time_dim) is not None,
+            host.td_lambda(gam, lam, nv, r, done, term, F.ALGO_AUTO, time_dim, True) is not None,
+            host.vtrace(gam, lp, lm, v, nv, r, done, term, 1.0, 1.0, F.ALGO_AUTO, time_dim) is not None)
+        fast[name] = (F.generalized_advantage_estimate(gam, lam, v, nv, r, done, term, time_dim=time_dim)
+                      + F.vec_generalized_advantage_estimate(gam, lam, v, nv, r, done, term, time_dim=time_dim)
+                      + F.gae_normalized(gam, lam, v, nv, r, done, term, eps=1e-4, time_dim=time_dim)
+                      + (F.td_lambda_return_estimate(gam, lam, nv, r, done, term, time_dim=time_dim),
+                         F.vec_td_lambda_return_estimate(gam, lam, nv, r, done, term, time_dim=time_dim))
+                      + F.vtrace_advantage_estimate(gam, lp, lm, v, nv, r, done, term, time_dim=time_dim))
+    monkeypatch.setattr(F, "_HOST", None)
+    for name, (gam, lam, eligible) in forms.items():
+        if eligible is None:
+            eligible = default_dtype == dtype
+        assert taken[name][0] == eligible, f"gae {name}: host module {'took' if taken[name][0] else 'declined'} the call"
+        if eligible:  # TD(lambda) and V-trace have laxer rules (scalars take the value dtype / lmbda is not theirs)
+            assert taken[name][1] and taken[name][2], f"{name}: td_lambda / vtrace declined"
+        slow = (F.generalized_advantage_estimate(gam, lam, v, nv, r, done, term, time_dim=time_dim)
+                + F.vec_generalized_advantage_estimate(gam, lam, v, nv, r, done, term, time_dim=time_dim)
+                + F.gae_normalized(gam, lam, v, nv, r, done, term, eps=1e-4, time_dim=time_dim)
+                + (F.td_lambda_return_estimate(gam, lam, nv, r, done, term, time_dim=time_dim),
+                   F.vec_td_lambda_return_estimate(gam, lam, nv, r, done, term, time_dim=time_dim))
+                + F.vtrace_advantage_estimate(gam, lp, lm, v, nv, r, done, term, time_dim=time_dim))
+        for k, (a, b) in enumerate(zip(fast[name], slow)):
+            assert a.dtype == b.dtype and a.shape == b.shape, (name, k, a.dtype, b.dtype)
+            assert torch.equal(a, b), f"{name} output {k}: max abs diff {(a - b).abs().max().item()}"
+
+
 def test_host_module_leaves_reference_errors_to_python():
     x = torch.zeros(2, 5, 1, device=DEV)
     m = torch.zeros(2, 5, 1, dtype=torch.bool, device=DEV)

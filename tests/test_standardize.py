@@ -124,5 +124,87 @@ def test_hip_ungrouped_small_and_large(n, dtype):
     g = torch.Generator().manual_seed(n)
     x = (torch.randn(n, generator=g, dtype=torch.float64) * 2 - 0.3).to(dtype)
     out = _standardize(x.to("cuda:0"), eps=1e-6)
-    assert F.last_kernel() == ("standardize_small" if n <= 65536 else "normalize")
+    assert F.last_kernel() == ("standardize_small" if n <= 65536 else "standardize_persistent")
     torch.testing.assert_close(out.cpu(), O.standardize(x, (), 1e-6), equal_nan=True, **tol(dtype))
+
+
+# ---- the one-launch route (persistent grid, values kept in registers across an in-launch gather of the block moments) --------
+def _big(shape, dtype, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g, dtype=torch.float32).to(torch.float64) * 3 + 1).to(dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,ex,kernel", [
+    ((4096, 100, 5, 1), (-2,), "standardize_grouped_persistent"),   # BASELINE config 3: MAPPO, agent dim kept independent
+    ((1000, 7, 3), (1,), "standardize_grouped_persistent"),         # inner > 1: period 21, 1008 of 1024 threads per tile
+    ((300000, 16), (1,), "standardize_grouped_persistent"),         # 16 groups: every wave of a block gathers one
+    ((64, 2, 512), (1,), "standardize_grouped_persistent"),         # period exactly 1024
+    ((1800000, 4), (1,), "standardize_grouped_persistent"),         # 28 values per thread
+    ((2200000, 4), (1,), "normalize_grouped"),                      # more than a thread keeps: moments -> reduce -> scale pass
+    ((50, 17, 2), (1,), "normalize_grouped"),                       # more than 16 groups
+    ((3, 2, 513), (1,), "normalize_grouped"),                       # period above 1024
+], ids=lambda v: "x".join(map(str, v)) if isinstance(v, tuple) else None)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_hip_grouped_one_launch(shape, ex, kernel, dtype):
+    from torchrl_amd._utils import _standardize
+    from torchrl_amd.objectives.value import functional as F
+
+    x = _big(shape, dtype)
+    xd = x.to("cuda:0")
+    out = _standardize(xd, ex, eps=1e-6)
+    assert F.last_kernel() == kernel
+    torch.testing.assert_close(out.cpu(), O.standardize(x, ex, 1e-6), **tol(dtype))
+    for _ in range(3):  # fixed reduction order: bitwise reproducible; the epoch protocol holds call after call
+        assert torch.equal(out, _standardize(xd, ex, eps=1e-6))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,offset,kernel", [(300000, 0, "standardize_persistent"), (3000000, 0, "standardize_persistent"),
+                                             (12000000, 0, "standardize_persistent"), (20000000, 0, "normalize"),
+                                             (2000001, 1, "standardize_persistent"), (7000003, 3, "standardize_persistent"),
+                                             (9000001, 1, "normalize")], ids=lambda v: str(v))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_hip_ungrouped_one_launch(n, offset, kernel, dtype):
+    """2 / 8 / 14 sixteen-byte vectors per thread, unaligned inputs (4- / 8-byte accesses, 8 or 28 values per thread), and the
+    sizes beyond what a thread keeps (two launches)."""
+    from torchrl_amd._utils import _standardize
+    from torchrl_amd.objectives.value import functional as F
+
+    if dtype == torch.float64 and n == 12000000:
+        kernel = "normalize"  # 14 vectors of 2: 7.3 M elements
+    x = _big(n + offset, dtype)[offset:]
+    xd = _big(n + offset, dtype).to("cuda:0")[offset:]
+    out = _standardize(xd, eps=1e-6)
+    assert F.last_kernel() == kernel
+    torch.testing.assert_close(out.cpu(), O.standardize(x, (), 1e-6), **tol(dtype))
+    assert torch.equal(out, _standardize(xd, eps=1e-6))
+
+
+@pytest.mark.gpu
+def test_one_launch_routes_share_the_workspace_with_the_fused_gae_step():
+    """`_standardize(x)` of a large tensor and the single-launch GAE + normalise use the same {epoch, slots} header of the
+    stream's workspace: 300 interleaved calls (more than the 8-bit tag's period) stay bit-identical to the first."""
+    from torchrl_amd._utils import _standardize
+    from torchrl_amd.objectives.value import functional as F
+
+    g = torch.Generator().manual_seed(11)
+    shape = (65536, 32, 1)
+    r, v, nv = (torch.randn(shape, generator=g).to("cuda:0") for _ in range(3))
+    term = (torch.rand(shape, generator=g) < 0.01).to("cuda:0")
+    done = term | (torch.rand(shape, generator=g) < 0.01).to("cuda:0")
+    x = _big((700001,), torch.float32).to("cuda:0")
+    y = _big((4096, 100, 5, 1), torch.float32, seed=6).to("cuda:0")
+    adv0, vt0 = F.gae_normalized(0.99, 0.95, v, nv, r, done, term, eps=1e-4)
+    assert F.last_kernel() == "gae_fused"
+    x0, y0 = _standardize(x), _standardize(y, (-2,))
+    for k in range(300):
+        for _ in range(k % 3):
+            xs = _standardize(x)
+        ys = _standardize(y, (-2,))
+        adv, vt = F.gae_normalized(0.99, 0.95, v, nv, r, done, term, eps=1e-4)
+        if k % 25 == 0 or k > 250:
+            assert torch.equal(adv, adv0) and torch.equal(vt, vt0) and torch.equal(ys, y0)
+            assert torch.equal(_standardize(x), x0)
+    torch.cuda.synchronize()
+    assert not F.workspace_error() and not F.fused_degraded()

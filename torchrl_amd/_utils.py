@@ -5,6 +5,7 @@ forms).  Same signature, validation, warning and error messages as the reference
 (extension) all-reduces the per-group moments of a batch sharded over ranks."""
 from __future__ import annotations
 
+import functools
 import math
 import warnings
 from typing import Optional, Tuple
@@ -17,13 +18,19 @@ from .objectives.value import functional as F
 
 __all__ = ["_standardize"]
 
-_SCRATCH = {}  # (device, stream) -> scratch buffer (per-group moments + partials)
+_SCRATCH = {}  # (device, stream, G) -> (per-group moments, workspace pointer, workspace bytes, buffer)
+_NEED = {}     # (outer, G, inner) -> trl_grouped_workspace_bytes
 
 
 def _grouped_pattern(shape, exclude_dims):
+    return _grouped_pattern_cached(tuple(shape), tuple(exclude_dims))
+
+
+@functools.lru_cache(maxsize=256)
+def _grouped_pattern_cached(shape, exclude_dims):
     """(outer, G, inner, permutation or None): excluded dims that are adjacent merge into one group
     axis of a contiguous tensor; otherwise they are permuted to the front."""
-    ex = sorted(exclude_dims)
+    shape, ex = list(shape), sorted(exclude_dims)
     if ex == list(range(ex[0], ex[-1] + 1)):
         return math.prod(shape[:ex[0]]), math.prod(shape[ex[0]:ex[-1] + 1]), math.prod(shape[ex[-1] + 1:]), None
     perm = ex + [d for d in range(len(shape)) if d not in ex]
@@ -72,33 +79,44 @@ def _standardize(input: Tensor, exclude_dims: Tuple[int] = (), mean: Optional[Te
         raise NotImplementedError(f"_standardize: dtype {input.dtype} unsupported (float32 / float64)")
     if input.numel() == 0:
         return input.clone()
-    outer, G, inner, perm = _grouped_pattern(list(shape), exclude_dims)
+    outer, G, inner, perm = _grouped_pattern(tuple(shape), tuple(exclude_dims))
     x = input.detach()
     x = x.contiguous() if perm is None else x.permute(perm).contiguous()
     dev = x.device
-    head = ((G * 24 + 255) // 256) * 256  # the per-group moments live at the head of the scratch buffer
-    need = head + lib.trl_grouped_workspace_bytes(outer, G, inner)
-    key = (dev.index, F._stream(dev))
-    ws = _SCRATCH.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _SCRATCH[key] = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=dev)
-    stats = ws[:G * 24].view(torch.float64)
-    wsp, wsn = ws.data_ptr() + head, ws.numel() - head
+    stream = F._stream(dev)
+    stats, wsp, wsn = _scratch(lib, dev, stream, outer, G, inner)
     out = torch.empty_like(x)
     sharded = group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1
+    dt = F._DT[x.dtype]
     with F._on(dev):
-        if not sharded:  # one C-ABI call: moments -> per-group reduce -> scale pass
-            _extension.check(lib.trl_standardize_grouped(F._stream(dev), F._DT[x.dtype], F._ptr(x), outer, G, inner, float(eps),
-                                                         F._ptr(out), F._ptr(stats), wsp, wsn), lib)
+        if not sharded:
+            # one C-ABI call; ONE launch for G <= 16 groups of period G * inner <= 1024 (values kept in registers across an
+            # in-launch gather of the block moments), else moments -> per-group reduce -> scale pass
+            rc = lib.trl_standardize_grouped(stream, dt, x.data_ptr(), outer, G, inner, float(eps), out.data_ptr(), stats.data_ptr(), wsp, wsn)
+            if rc:
+                _extension.check(rc, lib)
         else:
-            _extension.check(lib.trl_moments_grouped(F._stream(dev), F._DT[x.dtype], F._ptr(x), outer, G, inner, F._ptr(stats),
-                                                     wsp, wsn), lib)
+            _extension.check(lib.trl_moments_grouped(stream, dt, F._ptr(x), outer, G, inner, F._ptr(stats), wsp, wsn), lib)
             torch.distributed.all_reduce(stats, group=group)
-            _extension.check(lib.trl_normalize_grouped(F._stream(dev), F._DT[x.dtype], F._ptr(x), outer, G, inner, F._ptr(stats),
-                                                       float(eps), F._ptr(out)), lib)
+            _extension.check(lib.trl_normalize_grouped(stream, dt, F._ptr(x), outer, G, inner, F._ptr(stats), float(eps), F._ptr(out)), lib)
     if perm is not None:
         inv = [0] * len(perm)
         for k, d in enumerate(perm):
             inv[d] = k
         out = out.permute(inv).contiguous()
     return out.view(shape)
+
+
+def _scratch(lib, dev, stream, outer, G, inner):
+    """(per-group moments tensor, workspace pointer, workspace bytes) on (device, stream): one buffer, ZERO-FILLED when
+    created (include/trl_value.h: the grouped workspace carries the epoch of the one-launch route), the moments at its head."""
+    key = (dev.index, stream, G)
+    hit = _SCRATCH.get(key)
+    need = _NEED.get((outer, G, inner))
+    if need is None:
+        need = _NEED[(outer, G, inner)] = lib.trl_grouped_workspace_bytes(outer, G, inner)
+    if hit is None or hit[2] < need:
+        head = ((G * 24 + 255) // 256) * 256
+        buf = torch.zeros(head + max(need, 1 << 16), dtype=torch.uint8, device=dev)
+        hit = _SCRATCH[key] = (buf[:G * 24].view(torch.float64), buf.data_ptr() + head, buf.numel() - head, buf)
+    return hit[0], hit[1], hit[2]

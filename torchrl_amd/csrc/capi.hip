@@ -118,13 +118,13 @@ static bool fused_degraded() {
 }
 
 static const char kGaveUpText[] =
-    "an EARLIER single-launch GAE + normalise call on this GPU gave up waiting for its other blocks (its persistent grid was "
-    "not co-resident: another kernel held compute units); that call left the advantage UN-NORMALISED";
+    "an EARLIER single-launch call (GAE + normalise, or standardize) on this GPU gave up waiting for its other blocks (its "
+    "persistent grid was not co-resident: another kernel held compute units); that call left its output UN-NORMALISED";
 
 // status of a call that did its work: TRL_OK, or -- once, on the call that noticed the give-up -- the degrade warning
 static int done_ok(const char *fn, bool saw_failure) {
     if (!saw_failure) return TRL_OK;
-    return fail(TRL_WARN_FUSED_DEGRADED, "%s: completed, but %s.  TRL_ALGO_AUTO now uses the two-launch route on this GPU "
+    return fail(TRL_WARN_FUSED_DEGRADED, "%s: completed, but %s.  TRL_ALGO_AUTO now uses the multi-launch routes on this GPU "
                 "(trl_fused_reset() re-arms the single launch).", fn, kGaveUpText);
 }
 
@@ -649,17 +649,28 @@ int trl_normalize(void *stream, int dtype, const void *x, int64_t n, const doubl
 
 int trl_standardize(void *stream, int dtype, const void *x, int64_t n, double eps, void *out, double *stats,
                     void *workspace, size_t workspace_bytes) {
+    const bool saw_failure = observe_fused_failure();
     if (!dtype_ok(dtype)) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_standardize: bad dtype");
     if (n <= 0 || !x || !out) return fail(TRL_ERR_INVALID_ARGUMENT, "trl_standardize: null pointer or n <= 0");
     if (standardize_small_ok(n)) {
         launch_standardize_small((hipStream_t)stream, dtype, x, n, eps, out, stats);
         if (int rc = check_launch("trl_standardize")) return rc;
         g_kernel = "standardize_small";
-        return TRL_OK;
+        return done_ok("trl_standardize", saw_failure);
     }
     if (!workspace || workspace_bytes < trl_workspace_bytes(n, 1, 1) || ((uintptr_t)workspace & 7))
         return fail(TRL_ERR_WORKSPACE, "trl_standardize: workspace is %zu bytes, need %zu (8-byte aligned)", workspace_bytes,
                     trl_workspace_bytes(n, 1, 1));
+    // one persistent launch (values kept in registers across an in-launch gather of the block moments; the workspace head
+    // is the same {epoch, error, slots} header the single-launch GAE + normalise uses) unless the device is degraded
+    if (!fused_degraded() && ((uintptr_t)workspace & 255) == 0) {
+        const int rc = launch_standardize_persistent((hipStream_t)stream, dtype, x, n, 1, 1, eps, out, workspace, false, stats, fused_flag(true));
+        if (rc == 0) {
+            if (int rc2 = check_launch("trl_standardize(persistent)")) return rc2;
+            g_kernel = "standardize_persistent";
+            return done_ok("trl_standardize", saw_failure);
+        }
+    }
     // two launches: per-block moments, then a scale pass whose blocks sum the (<= 2048) partials themselves
     i64 np = 0;
     double *partials = (double *)((char *)workspace + kWsPartialsOffset);
@@ -668,18 +679,33 @@ int trl_standardize(void *stream, int dtype, const void *x, int64_t n, double ep
     launch_normalize_from_partials((hipStream_t)stream, dtype, x, n, partials, np, (double)n, eps, out, stats, 0);
     if (int rc = check_launch("trl_standardize(normalize)")) return rc;
     g_kernel = "normalize";
-    return TRL_OK;
+    return done_ok("trl_standardize", saw_failure);
 }
 
+// grouped workspace: [0, kPersistentNormWsBytes) {epoch, error, slots} of the one-launch route, then the per-block partials
+// of the multi-launch route
 int trl_standardize_grouped(void *stream, int dtype, const void *x, int64_t outer, int64_t G, int64_t inner, double eps, void *out,
                             double *stats, void *workspace, size_t workspace_bytes) {
+    const bool saw_failure = observe_fused_failure();
+    if (dtype_ok(dtype) && outer > 0 && G > 0 && inner > 0 && x && out && stats && workspace && ((uintptr_t)workspace & 255) == 0 &&
+        workspace_bytes >= trl_grouped_workspace_bytes(outer, G, inner) && !fused_degraded() &&
+        check_dims("trl_standardize_grouped", outer, G, inner) == TRL_OK) {
+        const int rc = launch_standardize_persistent((hipStream_t)stream, dtype, x, outer, G, inner, eps, out, workspace, true, stats,
+                                                     fused_flag(true));
+        if (rc == 0) {
+            if (int rc2 = check_launch("trl_standardize_grouped(persistent)")) return rc2;
+            g_kernel = "standardize_grouped_persistent";
+            return done_ok("trl_standardize_grouped", saw_failure);
+        }
+    }
     if (int rc = trl_moments_grouped(stream, dtype, x, outer, G, inner, stats, workspace, workspace_bytes)) return rc;
-    return trl_normalize_grouped(stream, dtype, x, outer, G, inner, stats, eps, out);
+    if (int rc = trl_normalize_grouped(stream, dtype, x, outer, G, inner, stats, eps, out)) return rc;
+    return done_ok("trl_standardize_grouped", saw_failure);
 }
 
 size_t trl_grouped_workspace_bytes(int64_t outer, int64_t G, int64_t inner) {
     if (outer <= 0 || G <= 0 || inner <= 0) return 0;
-    return (size_t)G * (size_t)grouped_blocks_per_group(outer, G, inner) * 2 * sizeof(double) + 256;
+    return kPersistentNormWsBytes + (size_t)G * (size_t)grouped_blocks_per_group(outer, G, inner) * 2 * sizeof(double) + 256;
 }
 
 int trl_moments_grouped(void *stream, int dtype, const void *x, int64_t outer, int64_t G, int64_t inner, double *stats,
@@ -691,7 +717,7 @@ int trl_moments_grouped(void *stream, int dtype, const void *x, int64_t outer, i
     if (!workspace || workspace_bytes < trl_grouped_workspace_bytes(outer, G, inner) || ((uintptr_t)workspace & 7))
         return fail(TRL_ERR_WORKSPACE, "trl_moments_grouped: workspace is %zu bytes, need %zu (8-byte aligned)", workspace_bytes,
                     trl_grouped_workspace_bytes(outer, G, inner));
-    launch_moments_grouped((hipStream_t)stream, dtype, x, outer, G, inner, (double *)workspace, stats);
+    launch_moments_grouped((hipStream_t)stream, dtype, x, outer, G, inner, (double *)((char *)workspace + kPersistentNormWsBytes), stats);
     if (int rc = check_launch("trl_moments_grouped")) return rc;
     g_kernel = "moments_grouped";
     return TRL_OK;

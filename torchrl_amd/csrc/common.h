@@ -82,8 +82,10 @@ __device__ __forceinline__ void block_sum2(double &s, double &ss, double *smem /
 template <typename TS>
 __host__ __device__ __forceinline__ void mean_std(double n, double s, double ss, double eps, TS &mean_s, TS &std_s) {
     const double mean = s / n;
-    double var = (ss - n * mean * mean) / (n - 1.0);  // unbiased, as torch.std
-    if (var < 0.0) var = 0.0;                         // rounding only; NaN (n == 1) stays NaN
+    // unbiased, as torch.std; one element: NaN as torch gives (0 / 0 when the sums are exact -- said explicitly because the
+    // in-launch gathers truncate the sums to 45 mantissa bits, moment_gather.h)
+    double var = n == 1.0 ? __builtin_nan("") : (ss - n * mean * mean) / (n - 1.0);
+    if (var < 0.0) var = 0.0;                         // rounding only; NaN stays NaN
     mean_s = (TS)mean;
     std_s = (TS)sqrt(var);
     const TS eps_s = (TS)eps;
@@ -215,6 +217,13 @@ int launch_normalize_grouped(hipStream_t s, int dt, const void *x, i64 outer, i6
                              void *out);
 int launch_normalize_from_partials(hipStream_t s, int dt, const void *x, i64 n, const double *partials, i64 npartials,
                                    double n_total, double eps, void *out, double *stats_out, int nblocks_hint);
+
+// standardize in one persistent launch (norm_kernels.hip); status 2 = not eligible.  ws: {epoch, error, slots} header
+// (zero-filled once): the head of a trl_workspace_bytes() workspace (grouped_ws = false, G == 1) or a region of
+// kPersistentNormWsBytes (grouped_ws = true, G <= 16)
+constexpr size_t kPersistentNormWsBytes = 256 + (size_t)16 * 4 * 256 * 16;  // header + 16 groups x 4 replicas x 256 blocks x 16 B
+int launch_standardize_persistent(hipStream_t s, int dt, const void *x, i64 outer, i64 G, i64 inner, double eps, void *out, void *ws,
+                                  bool grouped_ws, double *stats_out, unsigned *host_flag);
 
 // Fused single-launch GAE + normalisation (fused_kernels.hip).  status 2 = shape not eligible.
 constexpr size_t kFusedWsBytes = 256 + 4 * 512 * 128;  // header + 4 replicas of one 128-byte slot line per block, at the start of the workspace

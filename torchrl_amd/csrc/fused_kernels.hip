@@ -37,6 +37,7 @@
 // held CUs) writes the UN-NORMALISED advantage, sets the workspace's error word and raises the host-visible flag
 // (capi.hip: the next call on this GPU returns TRL_ERR_LAUNCH) -- never NaNs, never silently.
 #include "scan_core.h"
+#include "moment_gather.h"
 #include "xchg.h"
 #include <cstdlib>
 
@@ -46,42 +47,11 @@ using namespace scan;
 
 constexpr int kTeams = 4;
 constexpr int kFusedThreads = kTeams * kTeam;  // 1024
-constexpr int kMaxBlocks = 512;                // slots available in the workspace header
+constexpr int kMaxBlocks = gather::kMaxBlocks;  // slots available in the workspace header
 
-struct FusedWs {
-    unsigned epoch;
-    unsigned error;
-    unsigned pad[62];
-    unsigned long long slots[1];  // kSlotReplicas packed arrays of gridDim.x 16-byte granules
-};
-// Packed granules, 8 replicas (block b sweeps replica b % 8).  Measured at C4 (kfused3.hip): 1 / 4 / 8 / 16 / 32 replicas
-// 7.81 / 7.48 / 7.45 / 7.49 / 7.58 us per launch; one 128-byte line per block (round 2) 7.95; line strides of 256 B - 16 KB
-// no better; two-level gathers (16 x 16, 8 x 32 groups) 7.5 - 7.7; two poll rounds in flight: slower (kxchg.hip).
-constexpr int kSlotReplicas = 8;
+typedef gather::Header FusedWs;  // {epoch, error, slots}: kSlotReplicas packed arrays of gridDim.x 16-byte granules (moment_gather.h)
+constexpr int kSlotReplicas = gather::kHeaderReplicas;   // block b sweeps replica b % 8 (replica counts and layouts measured: moment_gather.h)
 static_assert(256 + (size_t)kSlotReplicas * kMaxBlocks * 16 <= kFusedWsBytes, "workspace header");
-
-typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-// one write-through 16-byte store (the s_nop: see store_wt)
-__device__ __forceinline__ void store_granule(unsigned long long *p, unsigned long long a, unsigned long long b) {
-    u64x2 v = {a, b};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-// four agent-scope 16-byte loads issued together, one wait (sc1: served from the memory side, never a stale L2 line)
-__device__ __forceinline__ void load_granules4(const unsigned long long *p0, const unsigned long long *p1, const unsigned long long *p2,
-                                               const unsigned long long *p3, u64x2 &v0, u64x2 &v1, u64x2 &v2, u64x2 &v3) {
-    asm volatile(
-        "global_load_dwordx4 %0, %4, off sc1\n\t"
-        "global_load_dwordx4 %1, %5, off sc1\n\t"
-        "global_load_dwordx4 %2, %6, off sc1\n\t"
-        "global_load_dwordx4 %3, %7, off sc1\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
-        : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
-        : "memory");
-}
-__device__ __forceinline__ bool granule_ok(const u64x2 &v, unsigned tag) {
-    return ((unsigned)(v.x & 0xffull) == tag) && ((unsigned)(v.y & 0xffull) == tag);
-}
 
 struct FusedGeom {
     i64 O, T;
@@ -92,11 +62,6 @@ struct FusedGeom {
     double eps;
     unsigned *host_flag;  // device view of the library's pinned host word (may be null): raised when a launch gives up
 };
-
-__device__ __forceinline__ unsigned long long tag_bits(double x, unsigned tag) {
-    return ((unsigned long long)__double_as_longlong(x) & ~0xffull) | (unsigned long long)tag;
-}
-__device__ __forceinline__ double untag(unsigned long long b) { return __longlong_as_double((long long)(b & ~0xffull)); }
 
 // FULL: every team's K chunks are complete (nchunks == K * grid * kTeams, whole chunks of 256*V elements, aligned):
 //       no clipping, every lane holds V valid elements -- the C4 shape class; 0.6 us per launch at [65536 x 32].
@@ -198,39 +163,8 @@ __global__ __launch_bounds__(kFusedThreads) void gae_fused_kernel(typename Op::A
             bs += red[2 * k];
             bss += red[2 * k + 1];
         }
-        __builtin_amdgcn_s_setprio(3);  // the publish and the polls go ahead of the other waves' traffic (8.25 -> 8.18 us)
-        const int G = (int)gridDim.x;
-        constexpr int kRep = kSlotReplicas;
-        if (lane < kRep) store_granule(ws->slots + ((size_t)lane * G + blockIdx.x) * 2, tag_bits(bs, tag), tag_bits(bss, tag));
-        // lane l gathers blocks l, l + 64, ... of its replica: every round re-reads the whole array (4 KB at 256 blocks;
-        // re-polling only the missing granules saves nothing on coalesced loads)
-        const unsigned long long *rep = ws->slots + (size_t)(blockIdx.x % kRep) * G * 2;
-        const int i0 = lane, i1 = lane + 64, i2 = lane + 128, i3 = lane + 192;
-        auto at = [&](int i) { return rep + (size_t)(i < G ? i : G - 1) * 2; };  // lanes past the grid re-read the last granule
-        u64x2 v[8] = {};
-        const unsigned long long t_start = wall_clock64();
-        bool ok;
-        for (;;) {
-            load_granules4(at(i0), at(i1), at(i2), at(i3), v[0], v[1], v[2], v[3]);
-            ok = granule_ok(v[0], tag) && granule_ok(v[1], tag) && granule_ok(v[2], tag) && granule_ok(v[3], tag);
-            if (G > 4 * kWave) {  // grids of 257 - 512 blocks (kMaxBlocks)
-                load_granules4(at(i0 + 256), at(i1 + 256), at(i2 + 256), at(i3 + 256), v[4], v[5], v[6], v[7]);
-                ok = ok && granule_ok(v[4], tag) && granule_ok(v[5], tag) && granule_ok(v[6], tag) && granule_ok(v[7], tag);
-            }
-            if (__all(ok)) break;
-            if (wall_clock64() - t_start > 100000000ull) break;  // 1 s at 100 MHz: give up loudly
-            // no sleep between rounds (sleep 1 / 4: +0.03 / +0.1 us); a second round in flight: +0.1 us (kxchg.hip)
-        }
-        __builtin_amdgcn_s_setprio(0);
-        const bool all_ok = __all(ok);
-        if (!all_ok && lane < kRep)  // nothing this block published may match the NEXT launch's tag (see the header comment)
-            store_granule(ws->slots + ((size_t)lane * G + blockIdx.x) * 2, tag_bits(bs, (tag - 1u) & 0xffu), tag_bits(bss, (tag - 1u) & 0xffu));
-        double acc = 0.0, acq = 0.0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (lane + kWave * j < G) { acc += untag(v[j].x); acq += untag(v[j].y); }
-        acc = wave_sum(acc);
-        double tot_ss = wave_sum(acq);
+        double acc, tot_ss;
+        const bool all_ok = gather::publish_and_gather(ws->slots, kSlotReplicas, (int)gridDim.x, (int)blockIdx.x, tag, lane, bs, bss, acc, tot_ss);
         double tot_n = geo.n_total;
         bool x_ok = true;
         if constexpr (XCHG) {

@@ -7,13 +7,13 @@
 // loaded.
 //
 // gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated|None, eps|None, algo, time_dim)
-// td_lambda(gamma, lmbda, next_state_value, reward, done, terminated|None, algo, time_dim)
+// td_lambda(gamma, lmbda, next_state_value, reward, done, terminated|None, algo, time_dim, tensors_ok)
 // vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward, done, terminated|None, rho_thresh, c_thresh, algo, time_dim)
 //   -> the outputs (tuple / tensor) the call was made
 //   -> None                        not a fast-path call (python's general path takes it and raises the reference's errors)
 //   -> int                         non-zero status of the C-ABI call (python raises TrlError with trl_last_error())
-// Eligible: python-float coefficients / thresholds, dense same-shape float32 / float64 tensors of one dtype on the current HIP
-// device, bool masks either dense or per-step masks expanded (stride 0) over the dims after time, no autograd.  Scalar
+// Eligible: gamma / lmbda as python floats, 1-element tensors or tensors of the inputs' shape and dtype (parse_coef), python-float
+// thresholds, dense same-shape float32 / float64 tensors of one dtype on the current HIP device, bool masks either dense or per-step masks expanded (stride 0) over the dims after time, no autograd.  Scalar
 // coefficients are rounded here as functional._scalar_mask_coef / _round_to do (the reference's `gamma * int32_mask` takes
 // the torch default dtype, functional.py:172-174, 1322-1323; torch.full_like(values, gamma) the value dtype, :850-857).
 #include <torch/csrc/autograd/python_variable.h>
@@ -122,6 +122,41 @@ bool round_to(double x, at::ScalarType dt, double &out) {
     if (dt == at::kFloat) { out = (double)(float)x; return true; }
     return false;
 }
+
+// ---- gamma / lmbda / thresholds as the reference takes them -------------------------------------------------------------
+// python float; 1-element tensor (0-dim or [1], host or device: reading a device scalar synchronises, as float(x) in python
+// does); tensor of the inputs' shape (per-element coefficients, read in place).  Anything else declines.
+enum CoefKind { kPyFloat, kOneElement, kFull };
+struct Coef {
+    CoefKind kind = kPyFloat;
+    double val = 0.0;                     // python float as given / the tensor's one element
+    at::ScalarType dt = at::kDouble;      // tensor dtype (kOneElement, kFull)
+    const at::Tensor *t = nullptr;
+};
+bool parse_coef(PyObject *o, c10::IntArrayRef shape, const c10::Device &dev, Coef &c) {
+    if (PyFloat_CheckExact(o)) {
+        c.kind = kPyFloat;
+        c.val = PyFloat_AS_DOUBLE(o);
+        return true;
+    }
+    if (!THPVariable_Check(o)) return false;
+    const at::Tensor &t = THPVariable_Unpack(o);
+    const auto dt = t.scalar_type();
+    if (dt != at::kFloat && dt != at::kDouble) return false;
+    if (t.requires_grad() && c10::GradMode::is_enabled()) return false;
+    c.t = &t;
+    c.dt = dt;
+    if (t.numel() == 1) {
+        c.kind = kOneElement;
+        c.val = t.item<double>();
+        return true;
+    }
+    if (t.sizes() != shape || t.device() != dev || !t.is_contiguous()) return false;
+    c.kind = kFull;
+    return true;
+}
+int code_of(at::ScalarType dt) { return dt == at::kFloat ? TRL_F32 : TRL_F64; }
+at::ScalarType promote2(at::ScalarType a, at::ScalarType b) { return (a == at::kDouble || b == at::kDouble) ? at::kDouble : at::kFloat; }
 
 // the (device, stream) workspace when the call needs one: `always` (normalising call), else only for the look-back scan of few,
 // very long rows (functional._lookback_workspace)
@@ -233,10 +268,10 @@ PyObject *py_set_workspace(PyObject *, PyObject *args) {
 
 PyObject *py_gae(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
     if (!ready(nargs, 10, "gae")) return nullptr;
-    // coefficients: two python floats (rounded here), or (gamma, lmbda*gamma, coef dtype code) already rounded by python
-    // (functional.scalar_gae_coef: what the modules pass for their 0-dim buffers) with None in lmbda's place
+    // coefficients: python floats / 1-element tensors / tensors of the inputs' shape (parse_coef), or (gamma, lmbda*gamma, coef
+    // dtype code) already rounded by python (functional.scalar_gae_coef: what the modules pass for their 0-dim buffers) with
+    // None in lmbda's place
     const bool pre = PyTuple_CheckExact(a[0]) && a[1] == Py_None;
-    if (!pre && (!PyFloat_CheckExact(a[0]) || !PyFloat_CheckExact(a[1]))) Py_RETURN_NONE;
     for (int k = 2; k <= 5; ++k) DECLINE_UNLESS_TENSOR(a[k]);
     const bool has_term = a[6] != Py_None;
     if (has_term) DECLINE_UNLESS_TENSOR(a[6]);
@@ -251,17 +286,58 @@ PyObject *py_gae(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
     const int64_t td = PyLong_AsLongLong(a[9]);
     if (PyErr_Occurred()) return nullptr;
 
-    // gamma * int32_mask and (lmbda * gamma) * int32_mask: both take the default dtype (functional.py:172-174)
-    double g_val, lg_val;
+    // gamma * int32_mask and (lmbda * gamma) * int32_mask: python floats take the default dtype, floating tensors keep theirs
+    // (functional.py:172-174); the products are formed by ATen itself so that their rounding is torch's by construction
+    double g_val = 0.0, lg_val = 0.0, l_val = 0.0;
     int cdt;
+    const void *gamma_t = nullptr, *lg_t = nullptr;
+    at::Tensor keep_g, keep_lg;  // per-element coefficient tensors formed here
     if (pre) {
         if (!PyArg_ParseTuple(a[0], "ddi", &g_val, &lg_val, &cdt)) return nullptr;
         if (cdt != TRL_F32 && cdt != TRL_F64) Py_RETURN_NONE;
     } else {
-        const auto ddt = c10::get_default_dtype_as_scalartype();
-        if (!round_to(PyFloat_AS_DOUBLE(a[0]), ddt, g_val) || !round_to(PyFloat_AS_DOUBLE(a[1]) * PyFloat_AS_DOUBLE(a[0]), ddt, lg_val))
+        Coef g, l;
+        if (!parse_coef(a[0], nsv.sizes(), nsv.device(), g) || !parse_coef(a[1], nsv.sizes(), nsv.device(), l)) {
+            if (PyErr_Occurred()) return nullptr;
             Py_RETURN_NONE;
-        cdt = ddt == at::kFloat ? TRL_F32 : TRL_F64;
+        }
+        const auto ddt = c10::get_default_dtype_as_scalartype();
+        if (ddt != at::kFloat && ddt != at::kDouble) Py_RETURN_NONE;
+        const auto vdt = nsv.scalar_type();
+        try {
+            if (g.kind == kPyFloat && l.kind == kPyFloat) {
+                round_to(g.val, ddt, g_val);
+                round_to(l.val * g.val, ddt, lg_val);
+                cdt = code_of(ddt);
+            } else if (g.kind != kFull && l.kind != kFull) {  // scalar-like, at least one a tensor: `lmbda * gamma` as torch forms it
+                at::ScalarType g_dt = ddt;
+                if (g.kind == kPyFloat) round_to(g.val, ddt, g_val);
+                else { g_val = g.val; g_dt = g.dt; }
+                const at::Tensor prod = l.kind == kPyFloat ? at::mul(*g.t, at::Scalar(l.val))
+                                                           : (g.kind == kPyFloat ? at::mul(*l.t, at::Scalar(g.val)) : at::mul(*l.t, *g.t));
+                lg_val = prod.item<double>();
+                cdt = code_of(promote2(g_dt, prod.scalar_type()));
+            } else if (g.kind == kFull && l.kind != kFull) {  // lg = (coef)lmbda * gamma_t is formed in the kernel
+                if (g.dt != vdt || (l.kind == kOneElement && l.dt != vdt)) Py_RETURN_NONE;
+                gamma_t = g.t->data_ptr();
+                l_val = l.val;
+                cdt = code_of(g.dt);
+            } else {  // per-element lmbda: lmbda * gamma as a tensor, gamma per element too
+                keep_lg = g.kind == kPyFloat ? at::mul(*l.t, at::Scalar(g.val)) : at::mul(*l.t, *g.t);
+                const at::ScalarType g_dt = g.kind == kPyFloat ? ddt : g.dt;
+                if (keep_lg.scalar_type() != vdt || g_dt != vdt || keep_lg.sizes() != nsv.sizes()) Py_RETURN_NONE;
+                if (g.kind == kFull) gamma_t = g.t->data_ptr();
+                else {
+                    keep_g = at::full(nsv.sizes(), at::Scalar(g.val), nsv.options().dtype(g_dt));
+                    gamma_t = keep_g.data_ptr();
+                }
+                keep_lg = keep_lg.contiguous();
+                lg_t = keep_lg.data_ptr();
+                cdt = code_of(vdt);
+            }
+        } catch (const std::exception &) {  // mixed devices, ...: python's general path raises the reference's error
+            Py_RETURN_NONE;
+        }
     }
 
     const at::Tensor *vals[3] = {&nsv, &sv, &r};
@@ -279,11 +355,11 @@ PyObject *py_gae(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
     int rc;
     if (normalise)
         rc = g_gae_norm((void *)c.stream, c.vdt, cdt, r.data_ptr(), sv.data_ptr(), nsv.data_ptr(), (const uint8_t *)done.data_ptr(),
-                        (const uint8_t *)term.data_ptr(), c.bcast, nullptr, nullptr, g_val, 0.0, lg_val, c.O, c.T, c.I, adv.data_ptr(),
+                        (const uint8_t *)term.data_ptr(), c.bcast, gamma_t, lg_t, g_val, l_val, lg_val, c.O, c.T, c.I, adv.data_ptr(),
                         vt.data_ptr(), eps, nullptr, (void *)ws_ptr, ws_bytes, (int)algo);
     else
         rc = g_gae_fwd((void *)c.stream, c.vdt, cdt, r.data_ptr(), sv.data_ptr(), nsv.data_ptr(), (const uint8_t *)done.data_ptr(),
-                       (const uint8_t *)term.data_ptr(), c.bcast, nullptr, nullptr, g_val, 0.0, lg_val, c.O, c.T, c.I, adv.data_ptr(),
+                       (const uint8_t *)term.data_ptr(), c.bcast, gamma_t, lg_t, g_val, l_val, lg_val, c.O, c.T, c.I, adv.data_ptr(),
                        vt.data_ptr(), nullptr, (void *)ws_ptr, ws_bytes, (int)algo);
     PyObject *ret = nullptr;
     if (!call_ok(rc, &ret)) return ret;
@@ -291,8 +367,7 @@ PyObject *py_gae(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
 }
 
 PyObject *py_td_lambda(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
-    if (!ready(nargs, 8, "td_lambda")) return nullptr;
-    if (!PyFloat_CheckExact(a[0]) || !PyFloat_CheckExact(a[1])) Py_RETURN_NONE;
+    if (!ready(nargs, 9, "td_lambda")) return nullptr;
     for (int k = 2; k <= 4; ++k) DECLINE_UNLESS_TENSOR(a[k]);
     const bool has_term = a[5] != Py_None;
     if (has_term) DECLINE_UNLESS_TENSOR(a[5]);
@@ -302,7 +377,14 @@ PyObject *py_td_lambda(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
     const at::Tensor &term = has_term ? THPVariable_Unpack(a[5]) : done;
     const long algo = PyLong_AsLong(a[6]);
     const int64_t td = PyLong_AsLongLong(a[7]);
+    const bool tensors_ok = PyObject_IsTrue(a[8]) == 1;  // per-element coefficients: rolling gamma only (the caller knows)
     if (PyErr_Occurred()) return nullptr;
+    Coef g, l;
+    if (!parse_coef(a[0], nsv.sizes(), nsv.device(), g) || !parse_coef(a[1], nsv.sizes(), nsv.device(), l)) {
+        if (PyErr_Occurred()) return nullptr;
+        Py_RETURN_NONE;
+    }
+    if ((g.kind == kFull || l.kind == kFull) && !tensors_ok) Py_RETURN_NONE;
     const at::Tensor *vals[2] = {&nsv, &r};
     Call c;
     switch (canonical(vals, 2, done, term, td, c)) {
@@ -310,17 +392,19 @@ PyObject *py_td_lambda(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
         case kError: return nullptr;
         default: break;
     }
-    // torch.full_like(next_state_value, gamma): scalar coefficients take the value dtype (functional.py:850-857)
+    // torch.full_like(next_state_value, gamma): scalar-like coefficients take the value dtype (functional.py:850-857); a tensor
+    // of the inputs' shape is read per element (here: when it has the value dtype)
     double g_val = 0.0, l_val = 0.0;
-    round_to(PyFloat_AS_DOUBLE(a[0]), c.dt, g_val);
-    round_to(PyFloat_AS_DOUBLE(a[1]), c.dt, l_val);
+    const void *gamma_t = nullptr, *lmbda_t = nullptr;
+    if (g.kind == kFull) { if (g.dt != c.dt) Py_RETURN_NONE; gamma_t = g.t->data_ptr(); } else round_to(g.val, c.dt, g_val);
+    if (l.kind == kFull) { if (l.dt != c.dt) Py_RETURN_NONE; lmbda_t = l.t->data_ptr(); } else round_to(l.val, c.dt, l_val);
     uintptr_t ws_ptr;
     size_t ws_bytes;
     if (workspace_for(c, false, ws_ptr, ws_bytes) != kOk) return nullptr;
     at::Tensor out;
     if (!empty_like(nsv, c.dt, out)) return nullptr;
     const int rc = g_td_lambda((void *)c.stream, c.vdt, c.vdt, r.data_ptr(), nsv.data_ptr(), (const uint8_t *)done.data_ptr(),
-                               (const uint8_t *)term.data_ptr(), c.bcast, nullptr, nullptr, g_val, l_val, 1, c.O, c.T, c.I, out.data_ptr(),
+                               (const uint8_t *)term.data_ptr(), c.bcast, gamma_t, lmbda_t, g_val, l_val, 1, c.O, c.T, c.I, out.data_ptr(),
                                (void *)ws_ptr, ws_bytes, (int)algo);
     PyObject *ret = nullptr;
     if (!call_ok(rc, &ret)) return ret;
@@ -329,7 +413,7 @@ PyObject *py_td_lambda(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
 
 PyObject *py_vtrace(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
     if (!ready(nargs, 12, "vtrace")) return nullptr;
-    if (!PyFloat_CheckExact(a[0]) || !PyFloat_CheckExact(a[8]) || !PyFloat_CheckExact(a[9])) Py_RETURN_NONE;
+    if (!PyFloat_CheckExact(a[8]) || !PyFloat_CheckExact(a[9])) Py_RETURN_NONE;
     for (int k = 1; k <= 6; ++k) DECLINE_UNLESS_TENSOR(a[k]);
     const bool has_term = a[7] != Py_None;
     if (has_term) DECLINE_UNLESS_TENSOR(a[7]);
@@ -344,12 +428,21 @@ PyObject *py_vtrace(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
     const int64_t td = PyLong_AsLongLong(a[11]);
     if (PyErr_Occurred()) return nullptr;
     // gamma * int32_mask takes the default dtype; python thresholds become 0-dim default-dtype tensors (functional.py:1311-1323)
+    // a gamma tensor keeps its dtype (1-element: the scalar; inputs' shape: per element, read in place)
     const auto ddt = c10::get_default_dtype_as_scalartype();
-    double g_val, rho_hi, c_hi;
-    if (!round_to(PyFloat_AS_DOUBLE(a[0]), ddt, g_val) || !round_to(PyFloat_AS_DOUBLE(a[8]), ddt, rho_hi) ||
-        !round_to(PyFloat_AS_DOUBLE(a[9]), ddt, c_hi))
+    Coef g;
+    if (!parse_coef(a[0], nsv.sizes(), nsv.device(), g)) {
+        if (PyErr_Occurred()) return nullptr;
         Py_RETURN_NONE;
-    const int cdt = ddt == at::kFloat ? TRL_F32 : TRL_F64;
+    }
+    double g_val = 0.0, rho_hi, c_hi;
+    if (!round_to(PyFloat_AS_DOUBLE(a[8]), ddt, rho_hi) || !round_to(PyFloat_AS_DOUBLE(a[9]), ddt, c_hi)) Py_RETURN_NONE;
+    at::ScalarType coef_dt = ddt;
+    const void *gamma_t = nullptr;
+    if (g.kind == kPyFloat) round_to(g.val, ddt, g_val);
+    else if (g.kind == kOneElement) { g_val = g.val; coef_dt = g.dt; }
+    else { gamma_t = g.t->data_ptr(); coef_dt = g.dt; }
+    const int cdt = code_of(coef_dt);
     const at::Tensor *vals[5] = {&nsv, &sv, &r, &lp, &lmu};
     Call c;
     switch (canonical(vals, 5, done, term, td, c)) {
@@ -360,11 +453,11 @@ PyObject *py_vtrace(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
     uintptr_t ws_ptr;
     size_t ws_bytes;
     if (workspace_for(c, false, ws_ptr, ws_bytes) != kOk) return nullptr;
-    const auto odt = (c.dt == at::kDouble || ddt == at::kDouble) ? at::kDouble : at::kFloat;  // promote(value, coefficient dtype)
+    const auto odt = promote2(c.dt, coef_dt);  // promote(value, coefficient dtype)
     at::Tensor adv, vs;
     if (!empty_like(nsv, odt, adv) || !empty_like(nsv, odt, vs)) return nullptr;
     const int rc = g_vtrace((void *)c.stream, c.vdt, cdt, lp.data_ptr(), lmu.data_ptr(), sv.data_ptr(), nsv.data_ptr(), r.data_ptr(),
-                            (const uint8_t *)done.data_ptr(), (const uint8_t *)term.data_ptr(), c.bcast, nullptr, g_val, rho_hi, c_hi,
+                            (const uint8_t *)done.data_ptr(), (const uint8_t *)term.data_ptr(), c.bcast, gamma_t, g_val, rho_hi, c_hi,
                             nullptr, nullptr, c.O, c.T, c.I, adv.data_ptr(), vs.data_ptr(), (void *)ws_ptr, ws_bytes, (int)algo);
     PyObject *ret = nullptr;
     if (!call_ok(rc, &ret)) return ret;
@@ -378,7 +471,7 @@ PyMethodDef methods[] = {
     {"gae", (PyCFunction)(void (*)(void))py_gae, METH_FASTCALL,
      "gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, eps, algo, time_dim)"},
     {"td_lambda", (PyCFunction)(void (*)(void))py_td_lambda, METH_FASTCALL,
-     "td_lambda(gamma, lmbda, next_state_value, reward, done, terminated, algo, time_dim)"},
+     "td_lambda(gamma, lmbda, next_state_value, reward, done, terminated, algo, time_dim, tensors_ok)"},
     {"vtrace", (PyCFunction)(void (*)(void))py_vtrace, METH_FASTCALL,
      "vtrace(gamma, log_pi, log_mu, state_value, next_state_value, reward, done, terminated, rho_thresh, c_thresh, algo, time_dim)"},
     {nullptr, nullptr, 0, nullptr}};

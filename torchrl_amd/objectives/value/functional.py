@@ -1386,7 +1386,7 @@ def td_lambda_return_estimate(
                                  -1 if rolling_gamma is None else int(bool(rolling_gamma)), time_dim, False)
     host = _HOST if _HOST_TRIED else _host_module()
     if host is not None and (rolling_gamma is None or rolling_gamma):
-        out = _host_call(host.td_lambda, gamma, lmbda, next_state_value, reward, done, terminated, ALGO_AUTO, time_dim)
+        out = _host_call(host.td_lambda, gamma, lmbda, next_state_value, reward, done, terminated, ALGO_AUTO, time_dim, True)
         if out is not None:
             return out
     call = _prepare_td_lambda(gamma, lmbda, next_state_value, reward, done, terminated, rolling_gamma, time_dim)
@@ -1416,8 +1416,9 @@ def vec_td_lambda_return_estimate(
         return _ops.td_lambda_op(next_state_value, reward, done, done if terminated is None else terminated, g, l, gt, lt,
                                  -1 if rolling_gamma is None else int(bool(rolling_gamma)), time_dim, True)
     host = _HOST if _HOST_TRIED else _host_module()
-    if host is not None:   # python-float coefficients: the reference's scalar path ignores rolling_gamma (functional.py:1101-1110)
-        out = _host_call(host.td_lambda, gamma, lmbda, next_state_value, reward, done, terminated, ALGO_AUTO, time_dim)
+    if host is not None:   # scalar coefficients: the reference's scalar path ignores rolling_gamma (functional.py:1101-1110)
+        out = _host_call(host.td_lambda, gamma, lmbda, next_state_value, reward, done, terminated, ALGO_AUTO, time_dim,
+                         rolling_gamma is None or bool(rolling_gamma))
         if out is not None:
             return out
     if terminated is None:
