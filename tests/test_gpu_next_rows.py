@@ -257,8 +257,8 @@ def test_host_module_takes_tensor_coefficients(shape, time_dim, dtype, default_d
         if eligible is None:
             eligible = default_dtype == dtype
         assert taken[name][0] == eligible, f"gae {name}: host module {'took' if taken[name][0] else 'declined'} the call"
-        if eligible:  # TD(lambda) and V-trace have laxer rules (scalars take the value dtype / lmbda is not theirs)
-            assert taken[name][1] and taken[name][2], f"{name}: td_lambda / vtrace declined"
+        if eligible:  # (a coefficient tensor of another dtype changes vec TD(lambda)'s output dtype: python's path)
+            assert taken[name][1] == (name != "zero_dim_host_other_dtype") and taken[name][2], f"{name}: td_lambda / vtrace"
         slow = (F.generalized_advantage_estimate(gam, lam, v, nv, r, done, term, time_dim=time_dim)
                 + F.vec_generalized_advantage_estimate(gam, lam, v, nv, r, done, term, time_dim=time_dim)
                 + F.gae_normalized(gam, lam, v, nv, r, done, term, eps=1e-4, time_dim=time_dim)

@@ -79,8 +79,8 @@ def main():
     # PPO-side _standardize on the C3 advantage, agent dim kept independent (one launch: 4 B read, 4 B written per element)
     from torchrl_amd._utils import _standardize
     adv = st.run()[0].view(shape)
-    report("C3 [4096x100x5] _standardize(exclude agent dim) f32", timeit(lambda: _standardize(adv, (-2,)), it), n, 8)
-    report("C3 [4096x100x5] _standardize(all dims) f32", timeit(lambda: _standardize(adv, ()), it), n, 8)
+    report("C3 [4096x100x5] _standardize(exclude agent dim) f32", timeit(lambda: _standardize(adv, (-2,)), 4 * it), n, 8)
+    report("C3 [4096x100x5] _standardize(all dims) f32", timeit(lambda: _standardize(adv, ()), 4 * it), n, 8)
     # the same two through the C ABI alone (fixed buffers): what the kernels cost without the Python host side
     from torchrl_amd import _extension as _ext
     from torchrl_amd import _utils as _u
@@ -88,10 +88,10 @@ def main():
     flat, o_ = adv.contiguous().view(-1), torch.empty_like(adv).view(-1)
     st_, wsp_, wsn_ = _u._scratch(lib_, flat.device, F._stream(flat.device), 409600, 5, 1)
     grouped = (F._stream(flat.device), 0, flat.data_ptr(), 409600, 5, 1, 1e-6, o_.data_ptr(), st_.data_ptr(), wsp_, wsn_)
-    report("C3 [4096x100x5] trl_standardize_grouped (C call only)", timeit(lambda: lib_.trl_standardize_grouped(*grouped), it), n, 8)
+    report("C3 [4096x100x5] trl_standardize_grouped (C call only)", timeit(lambda: lib_.trl_standardize_grouped(*grouped), 4 * it), n, 8)
     ws_ = F._workspace(lib_, flat.device, n, 1, 1)
     plain = (F._stream(flat.device), 0, flat.data_ptr(), n, 1e-6, o_.data_ptr(), None, ws_.data_ptr(), ws_.numel())
-    report("C3 [4096x100x5] trl_standardize (C call only)", timeit(lambda: lib_.trl_standardize(*plain), it), n, 8)
+    report("C3 [4096x100x5] trl_standardize (C call only)", timeit(lambda: lib_.trl_standardize(*plain), 4 * it), n, 8)
     # C4
     shape = (65536, 32, 1)
     r, v, nv, d, t, gam, lp, lm = inputs(shape, f32, 0.01)

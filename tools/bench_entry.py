@@ -38,7 +38,10 @@ for name, shape, td in (("C1 [1x2048]", (1, 2048, 1), -2), ("C2 [8x128]", (8, 12
     e_gae = per_call(lambda: F.generalized_advantage_estimate(0.99, 0.95, v, nv, r, done, term, time_dim=td))
     e_vec = per_call(lambda: F.vec_generalized_advantage_estimate(0.99, 0.95, v, nv, r, done, term, time_dim=td))
     e_norm = per_call(lambda: F.gae_normalized(0.99, 0.95, v, nv, r, done, term, eps=1e-4, time_dim=td))
-    e_gen = per_call(lambda: F.generalized_advantage_estimate(torch.tensor(0.99), 0.95, v, nv, r, done, term, time_dim=td))
+    g0, gfull = torch.tensor(0.99), torch.full(shape, 0.99, device=DEV)
+    e_gen = per_call(lambda: F.generalized_advantage_estimate(g0, 0.95, v, nv, r, done, term, time_dim=td))
+    e_full = per_call(lambda: F.generalized_advantage_estimate(gfull, 0.95, v, nv, r, done, term, time_dim=td))
+    e_td = per_call(lambda: F.td_lambda_return_estimate(gfull, 0.95, nv, r, done, term, time_dim=td))
     print(f"{name:16s} bound call: gae {k_gae:6.2f} us, gae+normalise {k_norm:6.2f} us | public API: generalized_advantage_estimate "
           f"{e_gae:6.2f} ({e_gae / k_gae:4.2f}x), vec {e_vec:6.2f}, gae_normalized {e_norm:6.2f} ({e_norm / k_norm:4.2f}x), "
-          f"general path (0-dim gamma tensor) {e_gen:6.2f}", flush=True)
+          f"0-dim gamma tensor {e_gen:6.2f}, full-shape gamma tensor {e_full:6.2f} (TD(lambda) {e_td:6.2f})", flush=True)

@@ -70,6 +70,15 @@ def _standardize(input: Tensor, exclude_dims: Tuple[int] = (), mean: Optional[Te
         else:
             std = torch.as_tensor(std, device=input.device)
         return (input - mean) / std.clamp_min(eps)
+    if group is None and input.__class__ is Tensor and not torch.compiler.is_compiling():
+        host = F._HOST if F._HOST_TRIED else F._host_module()
+        if host is not None:  # checks, output allocation and the C-ABI call in one C++ hop (csrc/host_fast.cpp)
+            out = host.standardize(input, tuple(exclude_dims), float(eps))
+            if out is not None:
+                if out.__class__ is int:
+                    _extension.check(out, _extension.get_lib())
+                else:
+                    return out
     if not n_ex:
         return F.standardize(input, eps, group=group).view(shape)
 
@@ -119,4 +128,7 @@ def _scratch(lib, dev, stream, outer, G, inner):
         head = ((G * 24 + 255) // 256) * 256
         buf = torch.zeros(head + max(need, 1 << 16), dtype=torch.uint8, device=dev)
         hit = _SCRATCH[key] = (buf[:G * 24].view(torch.float64), buf.data_ptr() + head, buf.numel() - head, buf)
+        if F._HOST:  # the host module mirrors this table: it must never keep the address of a replaced buffer
+            F._HOST.set_grouped_scratch(dev.index if dev.index is not None else torch.cuda.current_device(), stream, G,
+                                        hit[0].data_ptr(), hit[1], hit[2])
     return hit[0], hit[1], hit[2]

@@ -33,6 +33,15 @@ decltype(&trl_gae_normalize_fwd) g_gae_norm = nullptr;
 decltype(&trl_workspace_bytes) g_ws_bytes = nullptr;
 decltype(&trl_td_lambda_fwd) g_td_lambda = nullptr;
 decltype(&trl_vtrace_fwd) g_vtrace = nullptr;
+decltype(&trl_gae_bwd) g_gae_bwd = nullptr;
+decltype(&trl_td_lambda_bwd) g_td_lambda_bwd = nullptr;
+decltype(&trl_td1_bwd) g_td1_bwd = nullptr;
+decltype(&trl_last_kernel) g_last_kernel = nullptr;
+const char *g_last_bwd = "";  // kernel family of the last backward call made here (autograd calls from its own thread)
+decltype(&trl_standardize) g_standardize = nullptr;
+decltype(&trl_standardize_grouped) g_standardize_grouped = nullptr;
+decltype(&trl_grouped_workspace_bytes) g_grouped_bytes = nullptr;
+PyObject *g_scratch_cb = nullptr;  // (device index, outer, G, inner) -> None; python allocates the grouped scratch and calls set_grouped_scratch
 PyObject *g_ws_cb = nullptr;      // (device index, O, T, I) -> None; python allocates / grows the workspace and calls set_workspace
 PyObject *g_stream_cb = nullptr;  // torch._C._cuda_getCurrentRawStream
 
@@ -42,6 +51,20 @@ struct Workspace {
     size_t bytes;
 };
 std::vector<Workspace> g_ws;  // mirror of functional._WORKSPACES, kept current by set_workspace
+
+struct GroupedScratch {  // mirror of _utils._SCRATCH: per (device, stream, G) the per-group moments and the zero-filled workspace
+    int dev;
+    uintptr_t stream;
+    int64_t G;
+    uintptr_t stats, ptr;
+    size_t bytes;
+};
+std::vector<GroupedScratch> g_gs;
+GroupedScratch *find_gs(int dev, uintptr_t stream, int64_t G) {
+    for (auto &w : g_gs)
+        if (w.dev == dev && w.stream == stream && w.G == G) return &w;
+    return nullptr;
+}
 
 Workspace *find_ws(int dev, uintptr_t stream) {
     for (auto &w : g_ws)
@@ -198,9 +221,9 @@ bool call_ok(int rc, PyObject **ret) {
     if (rc == 0) return true;
     if (rc == TRL_WARN_FUSED_DEGRADED) {
         if (PyErr_WarnEx(PyExc_RuntimeWarning,
-                         "torchrl_amd: an earlier single-launch GAE + normalise call on this GPU gave up waiting for its other blocks "
-                         "and left its advantage UN-NORMALISED; GAE + normalise now takes the two-launch route on this GPU "
-                         "(functional.fused_reset() re-arms the single launch)", 1) < 0) {
+                         "torchrl_amd: an earlier single-launch call (GAE + normalise, or standardize) on this GPU gave up waiting "
+                         "for its other blocks and left its output UN-NORMALISED; those steps now take the multi-launch routes on "
+                         "this GPU (functional.fused_reset() re-arms the single launch)", 1) < 0) {
             *ret = nullptr;
             return false;
         }
@@ -231,21 +254,49 @@ bool ready(Py_ssize_t nargs, Py_ssize_t want, const char *name) {
 }
 
 PyObject *py_init(PyObject *, PyObject *args) {
-    unsigned long long a, b, c, d, e;
-    PyObject *ws_cb, *stream_cb;
-    if (!PyArg_ParseTuple(args, "KKKKKOO", &a, &b, &c, &d, &e, &ws_cb, &stream_cb)) return nullptr;
+    unsigned long long a, b, c, d, e, f, g, h, i, j, k, l;
+    PyObject *ws_cb, *stream_cb, *scratch_cb;
+    if (!PyArg_ParseTuple(args, "KKKKKKKKKKKKOOO", &a, &b, &c, &d, &e, &f, &g, &h, &i, &j, &k, &l, &ws_cb, &stream_cb, &scratch_cb))
+        return nullptr;
+    g_gae_bwd = (decltype(g_gae_bwd))(uintptr_t)i;
+    g_td_lambda_bwd = (decltype(g_td_lambda_bwd))(uintptr_t)j;
+    g_td1_bwd = (decltype(g_td1_bwd))(uintptr_t)k;
+    g_last_kernel = (decltype(g_last_kernel))(uintptr_t)l;
     g_gae_fwd = (decltype(g_gae_fwd))(uintptr_t)a;
     g_gae_norm = (decltype(g_gae_norm))(uintptr_t)b;
     g_ws_bytes = (decltype(g_ws_bytes))(uintptr_t)c;
     g_td_lambda = (decltype(g_td_lambda))(uintptr_t)d;
     g_vtrace = (decltype(g_vtrace))(uintptr_t)e;
+    g_standardize = (decltype(g_standardize))(uintptr_t)f;
+    g_standardize_grouped = (decltype(g_standardize_grouped))(uintptr_t)g;
+    g_grouped_bytes = (decltype(g_grouped_bytes))(uintptr_t)h;
     Py_XDECREF(g_ws_cb);
     Py_XDECREF(g_stream_cb);
+    Py_XDECREF(g_scratch_cb);
     Py_INCREF(ws_cb);
     Py_INCREF(stream_cb);
+    Py_INCREF(scratch_cb);
     g_ws_cb = ws_cb;
     g_stream_cb = stream_cb;
+    g_scratch_cb = scratch_cb;
     g_ws.clear();
+    g_gs.clear();
+    Py_RETURN_NONE;
+}
+
+PyObject *py_set_grouped_scratch(PyObject *, PyObject *args) {
+    int dev;
+    unsigned long long stream, stats, ptr, bytes;
+    long long G;
+    if (!PyArg_ParseTuple(args, "iKLKKK", &dev, &stream, &G, &stats, &ptr, &bytes)) return nullptr;
+    GroupedScratch *w = find_gs(dev, (uintptr_t)stream, G);
+    if (w) {
+        w->stats = (uintptr_t)stats;
+        w->ptr = (uintptr_t)ptr;
+        w->bytes = (size_t)bytes;
+    } else {
+        g_gs.push_back({dev, (uintptr_t)stream, (int64_t)G, (uintptr_t)stats, (uintptr_t)ptr, (size_t)bytes});
+    }
     Py_RETURN_NONE;
 }
 
@@ -396,8 +447,10 @@ PyObject *py_td_lambda(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
     // of the inputs' shape is read per element (here: when it has the value dtype)
     double g_val = 0.0, l_val = 0.0;
     const void *gamma_t = nullptr, *lmbda_t = nullptr;
-    if (g.kind == kFull) { if (g.dt != c.dt) Py_RETURN_NONE; gamma_t = g.t->data_ptr(); } else round_to(g.val, c.dt, g_val);
-    if (l.kind == kFull) { if (l.dt != c.dt) Py_RETURN_NONE; lmbda_t = l.t->data_ptr(); } else round_to(l.val, c.dt, l_val);
+    // (a coefficient tensor of another dtype -- 0-dim ones included -- changes the vec variant's output dtype: python's path)
+    if ((g.kind != kPyFloat && g.dt != c.dt) || (l.kind != kPyFloat && l.dt != c.dt)) Py_RETURN_NONE;
+    if (g.kind == kFull) gamma_t = g.t->data_ptr(); else round_to(g.val, c.dt, g_val);
+    if (l.kind == kFull) lmbda_t = l.t->data_ptr(); else round_to(l.val, c.dt, l_val);
     uintptr_t ws_ptr;
     size_t ws_bytes;
     if (workspace_for(c, false, ws_ptr, ws_bytes) != kOk) return nullptr;
@@ -464,10 +517,209 @@ PyObject *py_vtrace(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
     return pair(std::move(adv), std::move(vs));
 }
 
+// ---- backward launchers (functional._gae_bwd / _td_bwd in one hop) -------------------------------------------------------
+// incoming gradient as a dense tensor of dtype dt (None: the kernels read zeros)
+bool grad_in(PyObject *o, at::ScalarType dt, at::Tensor &keep, const void *&ptr) {
+    ptr = nullptr;
+    if (o == Py_None) return true;
+    if (!THPVariable_Check(o)) return false;
+    const at::Tensor &g = THPVariable_Unpack(o);
+    if (g.scalar_type() == dt && g.is_contiguous()) { ptr = g.data_ptr(); return true; }
+    keep = g.detach().to(dt).contiguous();
+    ptr = keep.data_ptr();
+    return true;
+}
+const void *ptr_or_null(PyObject *o) { return o == Py_None ? nullptr : THPVariable_Unpack(o).data_ptr(); }
+bool call_of(const at::Tensor &like, int64_t O, int64_t T, int64_t I, Call &c) {
+    const auto dev = like.device();
+    if (!dev.is_cuda() || c10::impl::getDeviceGuardImpl(c10::DeviceType::CUDA)->getDevice().index() != dev.index()) return false;
+    c.O = O; c.T = T; c.I = I;
+    c.dev = dev.index();
+    PyObject *dev_idx = PyLong_FromLong(c.dev);
+    PyObject *sres = PyObject_CallFunctionObjArgs(g_stream_cb, dev_idx, nullptr);
+    Py_DECREF(dev_idx);
+    if (!sres) return false;
+    c.stream = (uintptr_t)PyLong_AsUnsignedLongLong(sres);
+    Py_DECREF(sres);
+    return !PyErr_Occurred();
+}
+PyObject *wrap_or_none(at::Tensor &t) {
+    if (!t.defined()) Py_RETURN_NONE;
+    return THPVariable_Wrap(std::move(t));
+}
+
+// gae_bwd(g_adv|None, g_vt|None, like, done_u8, terminated_u8, mask_bcast, gamma_t|None, lg_t|None, gamma, lmbda, lg, O, T, I,
+//         coef dtype code, need_v, need_nv, need_r, algo) -> (d_state_value, d_next_state_value, d_reward) | None | int
+// `like`: a dense value tensor of the call (shape / dtype / device of the outputs); masks and coefficient tensors as the
+// prepared call holds them (functional._GaeCall)
+PyObject *py_gae_bwd(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
+    if (!ready(nargs, 19, "gae_bwd")) return nullptr;
+    for (int k : {2, 3, 4}) DECLINE_UNLESS_TENSOR(a[k]);
+    const at::Tensor &like = THPVariable_Unpack(a[2]);
+    const auto dt = like.scalar_type();
+    if (dt != at::kFloat && dt != at::kDouble) Py_RETURN_NONE;
+    const int64_t O = PyLong_AsLongLong(a[11]), T = PyLong_AsLongLong(a[12]), I = PyLong_AsLongLong(a[13]);
+    const int bcast = (int)PyLong_AsLong(a[5]), cdt = (int)PyLong_AsLong(a[14]), algo = (int)PyLong_AsLong(a[18]);
+    const double gamma = PyFloat_AsDouble(a[8]), lmbda = PyFloat_AsDouble(a[9]), lg = PyFloat_AsDouble(a[10]);
+    const bool need_v = PyObject_IsTrue(a[15]) == 1, need_nv = PyObject_IsTrue(a[16]) == 1, need_r = PyObject_IsTrue(a[17]) == 1;
+    if (PyErr_Occurred()) return nullptr;
+    if (!need_v && !need_nv && !need_r) Py_RETURN_NONE;
+    Call c;
+    if (!call_of(like, O, T, I, c)) { if (PyErr_Occurred()) return nullptr; Py_RETURN_NONE; }
+    at::Tensor keep_a, keep_v, d_v, d_nv, d_r;
+    const void *ga, *gv;
+    if (!grad_in(a[0], dt, keep_a, ga) || !grad_in(a[1], dt, keep_v, gv)) Py_RETURN_NONE;
+    if ((need_v && !empty_like(like, dt, d_v)) || (need_nv && !empty_like(like, dt, d_nv)) || (need_r && !empty_like(like, dt, d_r))) return nullptr;
+    uintptr_t ws_ptr;
+    size_t ws_bytes;
+    if (workspace_for(c, false, ws_ptr, ws_bytes) != kOk) return nullptr;
+    const int rc = g_gae_bwd((void *)c.stream, code_of(dt), cdt, ga, gv, (const uint8_t *)THPVariable_Unpack(a[3]).data_ptr(),
+                             (const uint8_t *)THPVariable_Unpack(a[4]).data_ptr(), bcast, ptr_or_null(a[6]), ptr_or_null(a[7]), gamma, lmbda, lg,
+                             O, T, I, need_r ? d_r.data_ptr() : nullptr, need_v ? d_v.data_ptr() : nullptr,
+                             need_nv ? d_nv.data_ptr() : nullptr, (void *)ws_ptr, ws_bytes, algo);
+    PyObject *ret = nullptr;
+    if (!call_ok(rc, &ret)) return ret;
+    g_last_bwd = g_last_kernel();
+    PyObject *out = PyTuple_New(3);
+    if (!out) return nullptr;
+    PyTuple_SET_ITEM(out, 0, wrap_or_none(d_v));
+    PyTuple_SET_ITEM(out, 1, wrap_or_none(d_nv));
+    PyTuple_SET_ITEM(out, 2, wrap_or_none(d_r));
+    return out;
+}
+
+// td_bwd(g_ret, like, done_u8, terminated_u8, mask_bcast, gamma_t|None, lmbda_t|None, gamma, lmbda, O, T, I, coef dtype code,
+//        td1, need_nv, need_r, algo) -> (d_next_state_value, d_reward) | None | int
+PyObject *py_td_bwd(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
+    if (!ready(nargs, 17, "td_bwd")) return nullptr;
+    for (int k : {0, 1, 2, 3}) DECLINE_UNLESS_TENSOR(a[k]);
+    const at::Tensor &like = THPVariable_Unpack(a[1]);
+    const auto dt = like.scalar_type();
+    if (dt != at::kFloat && dt != at::kDouble) Py_RETURN_NONE;
+    const int64_t O = PyLong_AsLongLong(a[9]), T = PyLong_AsLongLong(a[10]), I = PyLong_AsLongLong(a[11]);
+    const int bcast = (int)PyLong_AsLong(a[4]), cdt = (int)PyLong_AsLong(a[12]), algo = (int)PyLong_AsLong(a[16]);
+    const double gamma = PyFloat_AsDouble(a[7]), lmbda = PyFloat_AsDouble(a[8]);
+    const bool td1 = PyObject_IsTrue(a[13]) == 1, need_nv = PyObject_IsTrue(a[14]) == 1, need_r = PyObject_IsTrue(a[15]) == 1;
+    if (PyErr_Occurred()) return nullptr;
+    if (!need_nv && !need_r) Py_RETURN_NONE;
+    Call c;
+    if (!call_of(like, O, T, I, c)) { if (PyErr_Occurred()) return nullptr; Py_RETURN_NONE; }
+    at::Tensor keep, d_nv, d_r;
+    const void *gr;
+    if (!grad_in(a[0], dt, keep, gr)) Py_RETURN_NONE;
+    if ((need_nv && !empty_like(like, dt, d_nv)) || (need_r && !empty_like(like, dt, d_r))) return nullptr;
+    uintptr_t ws_ptr;
+    size_t ws_bytes;
+    if (workspace_for(c, false, ws_ptr, ws_bytes) != kOk) return nullptr;
+    const uint8_t *done = (const uint8_t *)THPVariable_Unpack(a[2]).data_ptr(), *term = (const uint8_t *)THPVariable_Unpack(a[3]).data_ptr();
+    const int rc = td1 ? g_td1_bwd((void *)c.stream, code_of(dt), cdt, gr, done, term, bcast, ptr_or_null(a[5]), gamma, O, T, I,
+                                   need_r ? d_r.data_ptr() : nullptr, need_nv ? d_nv.data_ptr() : nullptr, (void *)ws_ptr, ws_bytes, algo)
+                       : g_td_lambda_bwd((void *)c.stream, code_of(dt), cdt, gr, done, term, bcast, ptr_or_null(a[5]), ptr_or_null(a[6]),
+                                         gamma, lmbda, O, T, I, need_r ? d_r.data_ptr() : nullptr, need_nv ? d_nv.data_ptr() : nullptr,
+                                         (void *)ws_ptr, ws_bytes, algo);
+    PyObject *ret = nullptr;
+    if (!call_ok(rc, &ret)) return ret;
+    g_last_bwd = g_last_kernel();
+    PyObject *out = PyTuple_New(2);
+    if (!out) return nullptr;
+    PyTuple_SET_ITEM(out, 0, wrap_or_none(d_nv));
+    PyTuple_SET_ITEM(out, 1, wrap_or_none(d_r));
+    return out;
+}
+
+PyObject *py_last_bwd_kernel(PyObject *, PyObject *) { return PyUnicode_FromString(g_last_bwd); }
+
+// standardize(x, exclude_dims tuple, eps) -> tensor | None | int: `_standardize(x, exclude_dims)` without caller statistics
+// (reference: torchrl/_utils.py:875-936) for a dense float32 / float64 tensor on the current HIP device, no autograd; excluded
+// dims must be valid, distinct and ADJACENT (they merge into one group axis); everything else -- validation errors, the
+// all-dims-excluded warning, permuted group dims -- is python's.
+PyObject *py_standardize(PyObject *, PyObject *const *a, Py_ssize_t nargs) {
+    if (!ready(nargs, 3, "standardize")) return nullptr;
+    DECLINE_UNLESS_TENSOR(a[0]);
+    if (!PyTuple_CheckExact(a[1]) || !PyFloat_CheckExact(a[2])) Py_RETURN_NONE;
+    const at::Tensor &x = THPVariable_Unpack(a[0]);
+    const double eps = PyFloat_AS_DOUBLE(a[2]);
+    const auto dt = x.scalar_type();
+    const auto dev = x.device();
+    if ((dt != at::kFloat && dt != at::kDouble) || !dev.is_cuda() || !x.is_contiguous()) Py_RETURN_NONE;
+    if (x.requires_grad() && c10::GradMode::is_enabled()) Py_RETURN_NONE;
+    if (c10::impl::getDeviceGuardImpl(c10::DeviceType::CUDA)->getDevice().index() != dev.index()) Py_RETURN_NONE;
+    const int64_t n = x.numel(), nd = x.dim();
+    if (n == 0) Py_RETURN_NONE;
+    const Py_ssize_t n_ex = PyTuple_GET_SIZE(a[1]);
+    int64_t lo = nd, hi = -1;
+    uint64_t seen = 0;
+    if (n_ex >= nd || nd > 60) Py_RETURN_NONE;
+    for (Py_ssize_t k = 0; k < n_ex; ++k) {
+        PyObject *o = PyTuple_GET_ITEM(a[1], k);
+        if (!PyLong_CheckExact(o)) Py_RETURN_NONE;
+        int64_t d = PyLong_AsLongLong(o);
+        if (d < 0) d += nd;
+        if (d < 0 || d >= nd || (seen >> d) & 1) Py_RETURN_NONE;
+        seen |= 1ull << d;
+        lo = d < lo ? d : lo;
+        hi = d > hi ? d : hi;
+    }
+    if (n_ex > 0 && hi - lo + 1 != (int64_t)n_ex) Py_RETURN_NONE;  // not adjacent
+    PyObject *dev_idx = PyLong_FromLong(dev.index());
+    PyObject *sres = PyObject_CallFunctionObjArgs(g_stream_cb, dev_idx, nullptr);
+    Py_DECREF(dev_idx);
+    if (!sres) return nullptr;
+    const uintptr_t stream = (uintptr_t)PyLong_AsUnsignedLongLong(sres);
+    Py_DECREF(sres);
+    if (PyErr_Occurred()) return nullptr;
+    const int vdt = dt == at::kFloat ? TRL_F32 : TRL_F64;
+    at::Tensor out;
+    if (!empty_like(x, dt, out)) return nullptr;
+    int rc;
+    if (n_ex == 0) {
+        Call c;
+        c.O = n; c.T = 1; c.I = 1; c.dev = dev.index(); c.stream = stream;
+        uintptr_t ws_ptr = 0;
+        size_t ws_bytes = 0;
+        if (n > 65536) {  // up to a minibatch: one single-block launch, no workspace (trl_value.h)
+            // workspace_for's look-back rule does not apply here: ask for the workspace outright
+            if (workspace_for(c, true, ws_ptr, ws_bytes) != kOk) return nullptr;
+        }
+        rc = g_standardize((void *)stream, vdt, x.data_ptr(), n, eps, out.data_ptr(), nullptr, (void *)ws_ptr, ws_bytes);
+    } else {
+        auto shape = x.sizes();
+        int64_t outer = 1, G = 1, inner = 1;
+        for (int64_t k = 0; k < lo; ++k) outer *= shape[k];
+        for (int64_t k = lo; k <= hi; ++k) G *= shape[k];
+        for (int64_t k = hi + 1; k < nd; ++k) inner *= shape[k];
+        const size_t need = g_grouped_bytes(outer, G, inner);
+        GroupedScratch *w = find_gs(dev.index(), stream, G);
+        if (!w || w->bytes < need) {
+            PyObject *res = PyObject_CallFunction(g_scratch_cb, "iLLL", (int)dev.index(), (long long)outer, (long long)G, (long long)inner);
+            if (!res) return nullptr;
+            Py_DECREF(res);
+            w = find_gs(dev.index(), stream, G);
+            if (!w || w->bytes < need) {
+                PyErr_SetString(PyExc_RuntimeError, "_trl_host: scratch callback did not register a large enough grouped scratch");
+                return nullptr;
+            }
+        }
+        rc = g_standardize_grouped((void *)stream, vdt, x.data_ptr(), outer, G, inner, eps, out.data_ptr(), (double *)w->stats,
+                                   (void *)w->ptr, w->bytes);
+    }
+    PyObject *ret = nullptr;
+    if (!call_ok(rc, &ret)) return ret;
+    return THPVariable_Wrap(std::move(out));
+}
+
 PyMethodDef methods[] = {
     {"init", py_init, METH_VARARGS,
-     "init(trl_gae_fwd, trl_gae_normalize_fwd, trl_workspace_bytes, trl_td_lambda_fwd, trl_vtrace_fwd, ws_cb, stream_cb)"},
+     "init(trl_gae_fwd, trl_gae_normalize_fwd, trl_workspace_bytes, trl_td_lambda_fwd, trl_vtrace_fwd, trl_standardize, "
+     "trl_standardize_grouped, trl_grouped_workspace_bytes, trl_gae_bwd, trl_td_lambda_bwd, trl_td1_bwd, trl_last_kernel, ws_cb, "
+     "stream_cb, scratch_cb)"},
     {"set_workspace", py_set_workspace, METH_VARARGS, "set_workspace(device index, stream, pointer, bytes)"},
+    {"set_grouped_scratch", py_set_grouped_scratch, METH_VARARGS,
+     "set_grouped_scratch(device index, stream, G, moments pointer, workspace pointer, workspace bytes)"},
+    {"standardize", (PyCFunction)(void (*)(void))py_standardize, METH_FASTCALL, "standardize(x, exclude_dims, eps)"},
+    {"gae_bwd", (PyCFunction)(void (*)(void))py_gae_bwd, METH_FASTCALL, "gae_bwd(...): see host_fast.cpp"},
+    {"td_bwd", (PyCFunction)(void (*)(void))py_td_bwd, METH_FASTCALL, "td_bwd(...): see host_fast.cpp"},
+    {"last_bwd_kernel", py_last_bwd_kernel, METH_NOARGS, "kernel family of the last backward call made through this module"},
     {"gae", (PyCFunction)(void (*)(void))py_gae, METH_FASTCALL,
      "gae(gamma, lmbda, state_value, next_state_value, reward, done, terminated, eps, algo, time_dim)"},
     {"td_lambda", (PyCFunction)(void (*)(void))py_td_lambda, METH_FASTCALL,

@@ -485,6 +485,8 @@ _LAST_BWD_KERNEL = ""
 def last_bwd_kernel() -> str:
     """Kernel family of the last backward call.  (autograd runs backward on its own thread and trl_last_kernel is
     per thread, so the backward Functions record the name themselves.)"""
+    if _LAST_BWD_KERNEL is None:
+        return _HOST.last_bwd_kernel()
     return _LAST_BWD_KERNEL
 
 
@@ -546,6 +548,17 @@ def _next_in_time(x3, last):
 
 def _gae_bwd(c, g_adv, g_vt, need_v: bool, need_nv: bool, need_r: bool):
     """(d_state_value, d_next_state_value, d_reward) of GAE through trl_gae_bwd (None where not needed)."""
+    global _LAST_BWD_KERNEL
+    host = _HOST if _HOST_TRIED else _host_module()
+    if host is not None and c.reward.device.type == "cuda":  # allocations + the C-ABI call in one C++ hop (csrc/host_fast.cpp)
+        out = host.gae_bwd(g_adv, g_vt, c.reward, c.done, c.terminated, c.mask_bcast, c.gamma_t, c.lg_t, c.gamma, c.lmbda, c.lg,
+                           c.O, c.T, c.I, _DT[c.cdt], need_v, need_nv, need_r, _BWD_ALGO)
+        if out is not None:
+            if out.__class__ is int:
+                _extension.check(out, _extension.get_lib())
+            else:
+                _LAST_BWD_KERNEL = None  # asked of the host module on demand (last_bwd_kernel)
+                return out
     lib = _extension.get_lib()
     dev = c.reward.device
     ga, gv = _grad_in(g_adv, c, c.vdt), _grad_in(g_vt, c, c.vdt)
@@ -617,6 +630,17 @@ class _GaeFunction(torch.autograd.Function):
 
 def _td_bwd(c, g_ret, td1: bool, need_nv: bool, need_r: bool):
     """(d_next_state_value, d_reward) of TD(lambda) / TD(1) through trl_td_lambda_bwd / trl_td1_bwd."""
+    global _LAST_BWD_KERNEL
+    host = _HOST if _HOST_TRIED else _host_module()
+    if host is not None and c.reward.device.type == "cuda" and g_ret is not None:
+        out = host.td_bwd(g_ret, c.reward, c.done, c.terminated, c.mask_bcast, c.gamma_t, None if td1 else c.lmbda_t, c.gamma,
+                          1.0 if td1 else c.lmbda, c.O, c.T, c.I, _DT[c.cdt], td1, need_nv, need_r, _BWD_ALGO)
+        if out is not None:
+            if out.__class__ is int:
+                _extension.check(out, _extension.get_lib())
+            else:
+                _LAST_BWD_KERNEL = None
+                return out
     lib = _extension.get_lib()
     dev = c.reward.device
     gr = _grad_in(g_ret, c, c.vdt)
@@ -856,6 +880,12 @@ def _host_workspace(dev_index: int, O: int, T: int, I: int):
     _HOST.set_workspace(dev_index, _stream(dev), ws.data_ptr(), ws.numel())
 
 
+def _host_grouped_scratch(dev_index: int, outer: int, G: int, inner: int):
+    from ... import _utils
+    dev = torch.device("cuda", dev_index)
+    _utils._scratch(_extension.get_lib(), dev, _stream(dev), outer, G, inner)   # registers itself with the host module
+
+
 def _host_module():
     """Load and initialise csrc/host_fast.cpp's module (once); None when it is not there."""
     global _HOST, _HOST_TRIED
@@ -866,9 +896,16 @@ def _host_module():
             lib = _extension.get_lib()
             mod.init(_extension.fn_address(lib.trl_gae_fwd), _extension.fn_address(lib.trl_gae_normalize_fwd),
                      _extension.fn_address(lib.trl_workspace_bytes), _extension.fn_address(lib.trl_td_lambda_fwd),
-                     _extension.fn_address(lib.trl_vtrace_fwd), _host_workspace, torch._C._cuda_getCurrentRawStream)
+                     _extension.fn_address(lib.trl_vtrace_fwd), _extension.fn_address(lib.trl_standardize),
+                     _extension.fn_address(lib.trl_standardize_grouped), _extension.fn_address(lib.trl_grouped_workspace_bytes),
+                     _extension.fn_address(lib.trl_gae_bwd), _extension.fn_address(lib.trl_td_lambda_bwd),
+                     _extension.fn_address(lib.trl_td1_bwd), _extension.fn_address(lib.trl_last_kernel),
+                     _host_workspace, torch._C._cuda_getCurrentRawStream, _host_grouped_scratch)
             for (di, st), ws in _WORKSPACES.items():
                 mod.set_workspace(di, st, ws.data_ptr(), ws.numel())
+            from ... import _utils
+            for (di, st, G), hit in _utils._SCRATCH.items():
+                mod.set_grouped_scratch(di, st, G, hit[0].data_ptr(), hit[1], hit[2])
             _HOST = mod
     return _HOST
 
