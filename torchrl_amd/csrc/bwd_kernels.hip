@@ -195,9 +195,9 @@ struct VtraceBwdOp {
     static constexpr int V = V_;
     static constexpr bool kNeedsNext = true, kShifted = false, kReversed = true, kCustomEmit = true;
     // scan_impl.h: OpPrefetch*.  Two sets of the 10 input arrays spill in the 1024-thread short kernel; in the long kernel
-    // (256-thread blocks) fp32 gains more from the fourth wave per SIMD than from the prefetch, fp64 the other way round
-    // (C5 fp32 135 -> 114 us, fp64 261 with vs 325 without; C4 fp32 34 -> 23 us together with V = 2, fp64 99 -> 60).
-    static constexpr bool kPrefetchShort = false, kPrefetchLong = sizeof(TS_) == 8;
+    // (256-thread blocks) the extra wave per SIMD is worth more than the prefetch (C5 fp32 135 -> 114 us; fp64 at V = 1,
+    // dispatch_bwd_scan: 227 with, 225 without; C4 fp32 34 -> 23 us together with V = 2).
+    static constexpr bool kPrefetchShort = false, kPrefetchLong = false;
     static constexpr bool kDualScan = false;  // scan_impl.h: OpDualScan
     typedef TS TO;
     static constexpr int kNumOut = 1;
@@ -367,6 +367,12 @@ LaunchResult dispatch_bwd_scan(int vdt, int cdt, i64 T, F &&f) {
             if (cdt == 0) return f(OpT<float, float, 2>{});
             if (cdt == 1) return f(OpT<float, double, 2>{});
         }
+        // fp64: ONE element per lane (8-byte accesses).  V = 2 needs 164 VGPRs (3 waves per SIMD); V = 1 about half of that.
+        // Measured (round 3, tools/dev/bench_vtrace_bwd.py): C4 55.2 -> 36.2 us, C5 261.5 -> 225.0 us (4.15 -> 4.82 TB/s, the
+        // DRAM-bound rate of this box for a 1 GB footprint).  fp32 long rows with V = 2: 179 us (123 with the prefetch) against
+        // 115 with V = 4 -- there the per-chunk latency chain, not occupancy, is what counts.
+        if (vdt == 1 && cdt == 1) return f(OpT<double, double, 1>{});
+        if (vdt == 1 && cdt == 0) return f(OpT<double, float, 1>{});
     }
     return dispatch_scan<OpT, Args>(vdt, cdt, f);
 }

@@ -54,6 +54,8 @@ __device__ __forceinline__ Aff<TC> shfl_down_aff(const Aff<TC> &f, int off) {
 template <int BYTES>
 struct RawT;
 template <>
+struct RawT<1> { typedef unsigned char type; };
+template <>
 struct RawT<2> { typedef unsigned short type; };
 template <>
 struct RawT<4> { typedef unsigned int type; };
