@@ -166,6 +166,9 @@ int trl_gae_normalize_fwd(void *stream, int val_dtype, int coef_dtype,
  * process ends.  Calls no hipMalloc / hipFree or any allocating routine.  Problems whose trl_workspace_bytes(O, T, I)
  * exceeds the array are rejected with TRL_ERR_WORKSPACE.  Every call on a GPU shares that GPU's array (whatever the
  * stream): calls that overlap in time on one GPU race -- order them on one stream or with events.
+ * The FIRST call on a device (and the first call that reaches a given kernel) queries the runtime -- hipGetSymbolAddress,
+ * the occupancy of the persistent kernel -- and must therefore happen OUTSIDE graph capture; every later call only launches
+ * (tests/test_zz_no_alloc.py: free device memory unchanged across calls on every route; captured and replayed as a graph).
  */
 size_t trl_static_scratch_bytes(void);
 int trl_gae_normalize_fwd_noalloc(void *stream, int val_dtype, int coef_dtype,

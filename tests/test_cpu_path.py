@@ -318,3 +318,23 @@ def test_package_does_not_touch_the_oracle():
             "print('clean')\n")
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=ROOT))
     assert out.returncode == 0 and "clean" in out.stdout, out.stderr[-2000:]
+
+
+def test_in_place_update_between_forward_and_backward_raises():
+    """The backward kernels re-read the forward call's inputs: a rollout buffer modified in place in between must raise, as
+    torch's autograd does for its saved tensors, not give silently wrong gradients."""
+    g = torch.Generator().manual_seed(0)
+    shape = (4, 12, 1)
+    r, nv = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    v = torch.randn(shape, generator=g, requires_grad=True)
+    lp = torch.randn(shape, generator=g, requires_grad=True)
+    lm = torch.randn(shape, generator=g)
+    done = torch.rand(shape, generator=g) < 0.1
+    for fwd, victim in ((lambda: F.generalized_advantage_estimate(0.9, 0.8, v, nv, r, done)[0], done),
+                        (lambda: F.vtrace_advantage_estimate(0.9, lp, lm, v, nv, r, done)[0], nv)):
+        out = fwd()
+        out.sum().backward()  # untouched inputs: fine
+        out = fwd()
+        victim.mul_(0) if victim.dtype != torch.bool else victim.logical_not_()
+        with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+            out.sum().backward()

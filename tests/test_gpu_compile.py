@@ -82,3 +82,21 @@ def test_compiled_gradients_match_eager():
         grads.append([t.grad.clone() for t in (r, v, nv, lp, lmu)])
     for a, b in zip(*grads):
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+
+
+def test_compiled_nonrolling_td_gradients_match_eager():
+    """rolling_gamma=False under torch.compile: forward and backward (trl_td_fixed_bwd through its own custom op), as eager
+    (the compiled op used to raise as soon as an input required grad)."""
+    def loss(nv, r, gam, done, term):
+        ret = F.td_lambda_return_estimate(gam, 0.9, nv, r, done, term, rolling_gamma=False)
+        ret1 = F.td1_return_estimate(gam, nv, r, done, term, rolling_gamma=False)
+        return ret.pow(2).sum() + (ret1 * ret).sum()
+
+    grads = []
+    for fn in (loss, torch.compile(loss, fullgraph=True)):
+        r, v, nv, done, term, lp, lmu = _inputs((6, 30, 1), seed=4, grad=True)
+        gam = 0.9 + 0.1 * torch.rand((6, 30, 1), generator=torch.Generator().manual_seed(1)).to(DEV)
+        fn(nv, r, gam, done, term).backward()
+        grads.append([nv.grad.clone(), r.grad.clone()])
+    for a, b in zip(*grads):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)

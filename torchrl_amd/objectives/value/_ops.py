@@ -138,19 +138,44 @@ def _(g_ret, like, done, terminated, gamma, lmbda, gamma_t, lmbda_t, time_dim, v
     return torch.empty_like(like), torch.empty_like(like)
 
 
+@torch.library.custom_op(f"{_NS}::td_fixed_bwd", mutates_args=())
+def td_fixed_bwd_op(g_ret: Tensor, next_state_value: Tensor, reward: Tensor, done: Tensor, terminated: Tensor, gamma: float,
+                    lmbda: float, gamma_t: Optional[Tensor], lmbda_t: Optional[Tensor], time_dim: int, td1: bool) -> Tuple[Tensor, Tensor]:
+    """rolling_gamma=False (trl_td_fixed_bwd): needs the forward inputs, every start k reruns its own tail."""
+    if td1:
+        c = F._prepare_td1(_coef(gamma, gamma_t), next_state_value, reward, done, terminated, False, time_dim)
+    else:
+        c = F._prepare_td_lambda(_coef(gamma, gamma_t), _coef(lmbda, lmbda_t), next_state_value, reward, done, terminated, False, time_dim)
+    d_nv, d_r, _, _ = F._td_fixed_bwd(c, g_ret.reshape(reward.shape), td1, True, True, False, False)
+    return d_nv.view(reward.shape), d_r.view(reward.shape)
+
+
+@td_fixed_bwd_op.register_fake
+def _(g_ret, next_state_value, reward, done, terminated, gamma, lmbda, gamma_t, lmbda_t, time_dim, td1):
+    dt = F._check_value_dtype(reward, next_state_value)
+    return (torch.empty(reward.shape, dtype=dt, device=reward.device), torch.empty(reward.shape, dtype=dt, device=reward.device))
+
+
 def _td_setup(ctx, inputs, output):
     next_state_value, reward, done, terminated, gamma, lmbda, gamma_t, lmbda_t, rolling, time_dim, vec = inputs
-    if rolling == 0:
-        raise NotImplementedError("backward of td_lambda_return_estimate(rolling_gamma=False) is not implemented")
-    ctx.save_for_backward(done, terminated, gamma_t, lmbda_t)
+    ctx.fixed = rolling == 0 and (gamma_t is not None or lmbda_t is not None)  # rolling_gamma=False: trl_td_fixed_bwd (ADVICE r2)
+    if ctx.fixed:
+        ctx.save_for_backward(done, terminated, gamma_t, lmbda_t, next_state_value, reward)
+    else:
+        ctx.save_for_backward(done, terminated, gamma_t, lmbda_t)
     ctx.cfg = (gamma, lmbda, time_dim, vec, False)
     ctx.like = (reward.shape, F._check_value_dtype(reward, next_state_value), reward.device)
     ctx.dtypes = (next_state_value.dtype, reward.dtype)
 
 
 def _td_backward(ctx, g_ret):
-    done, terminated, gamma_t, lmbda_t = ctx.saved_tensors
     gamma, lmbda, time_dim, vec, td1 = ctx.cfg
+    if ctx.fixed:
+        done, terminated, gamma_t, lmbda_t, next_state_value, reward = ctx.saved_tensors
+        d_nv, d_r = td_fixed_bwd_op(g_ret.to(ctx.like[1]), next_state_value, reward, done, terminated, gamma, lmbda, gamma_t, lmbda_t,
+                                    time_dim, False)
+        return (d_nv.to(ctx.dtypes[0]), d_r.to(ctx.dtypes[1])) + (None,) * 9
+    done, terminated, gamma_t, lmbda_t = ctx.saved_tensors
     shape, dt, dev = ctx.like
     like = torch.empty(shape, dtype=dt, device=dev)
     d_nv, d_r = td_bwd_op(g_ret.to(dt), like, done, terminated, gamma, lmbda, gamma_t, lmbda_t, time_dim, vec, td1)
@@ -173,17 +198,24 @@ def _(next_state_value, reward, done, terminated, gamma, gamma_t, rolling, time_
 
 def _td1_setup(ctx, inputs, output):
     next_state_value, reward, done, terminated, gamma, gamma_t, rolling, time_dim = inputs
-    if rolling == 0:
-        raise NotImplementedError("backward of td1_return_estimate(rolling_gamma=False) is not implemented")
-    ctx.save_for_backward(done, terminated, gamma_t)
+    ctx.fixed = rolling == 0 and gamma_t is not None  # as _td_setup
+    if ctx.fixed:
+        ctx.save_for_backward(done, terminated, gamma_t, next_state_value, reward)
+    else:
+        ctx.save_for_backward(done, terminated, gamma_t)
     ctx.cfg = (gamma, time_dim)
     ctx.like = (reward.shape, F._check_value_dtype(reward, next_state_value), reward.device)
     ctx.dtypes = (next_state_value.dtype, reward.dtype)
 
 
 def _td1_backward(ctx, g_ret):
-    done, terminated, gamma_t = ctx.saved_tensors
     gamma, time_dim = ctx.cfg
+    if ctx.fixed:
+        done, terminated, gamma_t, next_state_value, reward = ctx.saved_tensors
+        d_nv, d_r = td_fixed_bwd_op(g_ret.to(ctx.like[1]), next_state_value, reward, done, terminated, gamma, 1.0, gamma_t, None,
+                                    time_dim, True)
+        return (d_nv.to(ctx.dtypes[0]), d_r.to(ctx.dtypes[1])) + (None,) * 6
+    done, terminated, gamma_t = ctx.saved_tensors
     shape, dt, dev = ctx.like
     like = torch.empty(shape, dtype=dt, device=dev)
     d_nv, d_r = td_bwd_op(g_ret.to(dt), like, done, terminated, gamma, 1.0, gamma_t, None, time_dim, False, True)

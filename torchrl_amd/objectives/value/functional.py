@@ -578,6 +578,25 @@ def _gae_bwd(c, g_adv, g_vt, need_v: bool, need_nv: bool, need_r: bool):
     return d_v, d_nv, d_r
 
 
+def _keep_call(ctx, call):
+    """Keep the prepared call for backward together with the version counters of its tensors.  The call holds detached
+    aliases of the caller's tensors (same storage, same version counter when no conversion was needed) and the backward
+    kernels re-read them: an in-place update of a rollout buffer between forward and backward must raise, as torch's own
+    autograd does for saved tensors, instead of giving silently wrong gradients."""
+    ctx.call = call
+    ctx.versions = tuple((name, t, t._version) for name, t in vars(call).items() if isinstance(t, torch.Tensor))
+
+
+def _kept_call(ctx):
+    for name, t, version in ctx.versions:
+        if t._version != version:
+            raise RuntimeError(
+                f"one of the variables needed for gradient computation has been modified by an inplace operation: the "
+                f"estimator's `{name}` input is at version {t._version}; expected version {version} (the backward kernels "
+                f"re-read the inputs of the forward call)")
+    return ctx.call
+
+
 class _GaeFunction(torch.autograd.Function):
     """``coefs = (gamma, lmbda, time_dim)`` as the caller passed them; ``gamma_e`` / ``lmbda_e`` are their
     differentiable full-shape views (:func:`_coef_leaf`) or None."""
@@ -588,7 +607,7 @@ class _GaeFunction(torch.autograd.Function):
             adv, vt, _ = _launch_gae(call)
         else:
             raise NotImplementedError("differentiable normalised GAE: normalise the differentiable advantage with torch ops")
-        ctx.call = call
+        _keep_call(ctx, call)
         ctx.coefs = coefs
         ctx.in_dtypes = (state_value.dtype, next_state_value.dtype, reward.dtype)
         ctx.in_shapes = (state_value.shape, next_state_value.shape, reward.shape)
@@ -599,7 +618,7 @@ class _GaeFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_adv, g_vt):
-        c = ctx.call
+        c = _kept_call(ctx)
         gamma_e, lmbda_e = ctx.leaves
         want_coef = gamma_e is not None or lmbda_e is not None
         none5 = (None, None, None, None, None)
@@ -693,7 +712,7 @@ def _td_fixed_bwd(c, g_ret, td1: bool, need_nv: bool, need_r: bool, need_gamma: 
 class _TdLambdaFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, next_state_value, reward, gamma_e, lmbda_e, call, out_dtype, coefs):
-        ctx.call = call
+        _keep_call(ctx, call)
         ctx.coefs = coefs
         ctx.in_dtypes = (next_state_value.dtype, reward.dtype)
         ctx.in_shapes = (next_state_value.shape, reward.shape)
@@ -705,7 +724,7 @@ class _TdLambdaFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_ret):
-        c = ctx.call
+        c = _kept_call(ctx)
         gamma_e, lmbda_e = ctx.leaves
         want_coef = gamma_e is not None or lmbda_e is not None
         if g_ret is None:
@@ -745,7 +764,7 @@ class _TdLambdaFunction(torch.autograd.Function):
 class _Td1Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, next_state_value, reward, gamma_e, call, out_dtype):
-        ctx.call = call
+        _keep_call(ctx, call)
         ctx.in_dtypes = (next_state_value.dtype, reward.dtype)
         ctx.in_shapes = (next_state_value.shape, reward.shape)
         ctx.gamma_e = gamma_e
@@ -756,7 +775,7 @@ class _Td1Function(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_ret):
-        c = ctx.call
+        c = _kept_call(ctx)
         if g_ret is None:
             return (None,) * 5
         need = ctx.needs_input_grad
@@ -823,7 +842,7 @@ class _VtraceFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, log_pi, log_mu, state_value, next_state_value, reward, gamma_e, call):
         adv, vs = _launch_vtrace(call)
-        ctx.call = call
+        _keep_call(ctx, call)
         ctx.gamma_e = gamma_e
         ctx.ins = tuple((t.dtype, t.shape) for t in (log_pi, log_mu, state_value, next_state_value, reward))
         ctx.save_for_backward(vs)
@@ -831,7 +850,7 @@ class _VtraceFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_adv, g_vs):
-        c = ctx.call
+        c = _kept_call(ctx)
         if g_adv is None and g_vs is None:
             return (None,) * 7
         (vs,) = ctx.saved_tensors
