@@ -160,6 +160,9 @@ def main():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1: strong = one [65536 x 32] batch sharded over the ranks (BASELINE config 4); weak = a full batch per rank")
     ap.add_argument("--no-cold", action="store_true", help="skip the cold (beyond-Infinity-Cache) leg")
+    ap.add_argument("--cold-only", action="store_true",
+                    help="profiling aid (tools/profile_bench.sh): run ONLY the cold leg's launches, so that rocprofv3's kernel "
+                         "statistics and PMC counters of this process describe the DRAM-bound launches alone; prints a short line")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -221,6 +224,27 @@ def main():
         ev[1].record()
         torch.cuda.synchronize()
         return ev[0].elapsed_time(ev[1]) / n
+
+    if args.cold_only:
+        if dist:
+            raise SystemExit("bench: --cold-only is a single-GPU profiling aid")
+        sets = []
+        for k in range(COLD_SETS):
+            ins = make_inputs(dev, seed=1000 + k)
+            ck = F._prepare_gae(GAMMA, LMBDA, ins[1], ins[2], ins[0], ins[3], ins[4], -2)
+            sets.append(F.prepare_gae_step(ck, EPS, normalize=True))
+        rounds = max(1, args.steps // COLD_SETS)
+
+        def cold_round():
+            for st in sets:
+                st.run()
+
+        for _ in range(max(1, args.warmup // COLD_SETS)):
+            cold_round()
+        ms = device_ms(cold_round, rounds) / COLD_SETS
+        print(json.dumps({"cold_only": True, "kernel": F.last_kernel(), "launches": rounds * COLD_SETS, "buffer_sets": COLD_SETS,
+                          "kernel_ms": ms, "achieved_gbs": O_ENVS * T_STEPS * BYTES_PER_TRANSITION / (ms * 1e-3) / 1e9}))
+        return
 
     exchange = {"tried": False, "ex": None}
 
