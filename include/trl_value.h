@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TRL_ABI_VERSION 7
+#define TRL_ABI_VERSION 8
 
 enum { TRL_F32 = 0, TRL_F64 = 1 };
 
@@ -53,7 +53,7 @@ enum {
     TRL_ERR_WORKSPACE = 3,        /* workspace missing or too small */
     TRL_ERR_LAUNCH = 4,           /* HIP reported a launch error */
     TRL_WARN_FUSED_DEGRADED = 100 /* NOT a failure: the call completed; reported once by the first call that notices that
-                                     an earlier single-launch GAE + normalise gave up (trl_fused_degraded) */
+                                     an earlier single-launch call (GAE + normalise, standardize) gave up (trl_fused_degraded) */
 };
 
 /* Kernel family.  AUTO picks by shape. */
@@ -92,11 +92,12 @@ size_t trl_workspace_bytes(int64_t O, int64_t T, int64_t I);
  * no-alloc entry point have no host flag (allocating it is an allocation): they learn of a give-up from this call, or from
  * `stats` (NaN sum / sumsq on a give-up). */
 int trl_workspace_error(const void *workspace);
-/* Failure semantics of the single-launch route (ABI 7).  A fused launch that gives up raises a word in pinned host memory
- * (allocated by the first fused launch of trl_gae_normalize_fwd / _xchg_fwd on a device).  The NEXT entry-point call on
+/* Failure semantics of the single-launch routes (ABI 7; ABI 8: trl_standardize / trl_standardize_grouped too).  A persistent
+ * launch that gives up raises a word in pinned host memory (allocated by the first such launch of trl_gae_normalize_fwd /
+ * _xchg_fwd / trl_standardize / trl_standardize_grouped on a device).  The NEXT entry-point call on
  * that GPU -- any estimator, trl_normalize -- notices it without synchronising and marks the device DEGRADED: from then on
  * TRL_ALGO_AUTO runs GAE + normalise as two launches (scan + scale pass; no co-residency needed, ~2x the time at
- * [65536 x 32]).  That call does its own work and returns TRL_WARN_FUSED_DEGRADED once; later calls return TRL_OK.
+ * [65536 x 32]) and the standardize calls as moments + scale pass.  That call does its own work and returns TRL_WARN_FUSED_DEGRADED once; later calls return TRL_OK.
  * Only an explicit TRL_ALGO_FUSED request fails (TRL_ERR_LAUNCH, on the call that notices the give-up).
  * trl_fused_degraded(): 1 if the current device is degraded, else 0.  trl_fused_reset(): re-arms the single launch on the
  * current device (the caller knows the GPU is its own again). */
@@ -329,8 +330,12 @@ int trl_moments(void *stream, int dtype, const void *x, int64_t n,
  * trl_moments + trl_normalize in one call (out-of-place or in place): `(x - x.mean()) / x.std().clamp_min(eps)`,
  * _standardize(x) without exclude_dims (torchrl/_utils.py:901-912) -- what PPO applies to every minibatch of
  * advantages (torchrl/objectives/ppo.py:688, 975, 1282).  n <= 65536 (a minibatch): ONE single-block launch,
- * no workspace needed; larger: moments -> reduce -> scale pass, needs `workspace` of
- * trl_workspace_bytes(n, 1, 1).  stats (optional, device double[3]) receives {N, sum, sumsq}.
+ * no workspace needed; larger: needs `workspace` of trl_workspace_bytes(n, 1, 1) and (ABI 8) runs as ONE persistent
+ * launch too -- #CUs co-resident blocks keep their share of x in registers across an in-launch gather of the block
+ * moments (the workspace header of the single-launch GAE + normalise: same rules, 256-byte aligned, zero-filled once;
+ * same failure semantics, see trl_fused_degraded) -- up to 56 fp32 / 28 fp64 values per thread (14.7 M / 7.3 M elements
+ * on 256 CUs); beyond that, on a degraded device or with a workspace that is only 8-byte aligned: moments -> scale pass
+ * (two launches).  stats (optional, device double[3]) receives {N, sum, sumsq}.
  */
 int trl_standardize(void *stream, int dtype, const void *x, int64_t n, double eps, void *out, double *stats,
                     void *workspace, size_t workspace_bytes);
@@ -348,13 +353,18 @@ int trl_standardize(void *stream, int dtype, const void *x, int64_t n, double ep
  *   the G*3 doubles before normalising.
  * trl_normalize_grouped: out = (x - mean_g) / max(std_g, eps), mean / std rounded to `dtype`
  *   as in trl_normalize.  out may alias x.
+ * trl_standardize_grouped: both in one call (single GPU); stats: device double[G*3], filled on the way.  ABI 8: ONE
+ *   persistent launch when G <= 16 and G*inner <= 1024 (the multi-agent case: a handful of agents, inner == 1) -- as
+ *   trl_standardize above, wave g of every block gathering group g -- else moments -> per-group reduce -> scale pass.
+ * ABI 8: the workspace of trl_grouped_workspace_bytes() starts with the {epoch, error, slots} header of the one-launch
+ *   route: it must be 256-byte aligned (8-byte alignment still works, on the multi-launch route) and ZERO-FILLED ONCE
+ *   before its first use; afterwards only this library writes it; calls that share it must not overlap in time.
  */
 size_t trl_grouped_workspace_bytes(int64_t outer, int64_t G, int64_t inner);
 int trl_moments_grouped(void *stream, int dtype, const void *x, int64_t outer, int64_t G, int64_t inner,
                         double *stats, void *workspace, size_t workspace_bytes);
 int trl_normalize_grouped(void *stream, int dtype, const void *x, int64_t outer, int64_t G, int64_t inner,
                           const double *stats, double eps, void *out);
-/* both of the above in one call (single GPU); stats: device double[G*3], filled on the way */
 int trl_standardize_grouped(void *stream, int dtype, const void *x, int64_t outer, int64_t G, int64_t inner,
                             double eps, void *out, double *stats, void *workspace, size_t workspace_bytes);
 

@@ -208,3 +208,37 @@ def test_one_launch_routes_share_the_workspace_with_the_fused_gae_step():
             assert torch.equal(_standardize(x), x0)
     torch.cuda.synchronize()
     assert not F.workspace_error() and not F.fused_degraded()
+
+
+@pytest.mark.gpu
+def test_small_fused_grids_keep_every_slot_fresh():
+    """Small batches run the single-launch GAE + normalise on a smaller persistent grid (one chunk per team); the slots of
+    the absent blocks are refreshed by every launch, so a full-grid launch exactly 256 launches (the 8-bit tag's period)
+    after the previous full-grid one cannot meet a stale granule whose tag matches: 255 small launches between two big ones,
+    twice, with a mid-sized grid mixed in; everything bit-identical to the first results."""
+    from torchrl_amd.objectives.value import functional as F
+
+    def batch(envs, seed):
+        g = torch.Generator().manual_seed(seed)
+        shape = (envs, 32, 1)
+        r, v, nv = (torch.randn(shape, generator=g).to("cuda:0") for _ in range(3))
+        term = (torch.rand(shape, generator=g) < 0.01).to("cuda:0")
+        done = term | (torch.rand(shape, generator=g) < 0.01).to("cuda:0")
+        return lambda: F.gae_normalized(0.99, 0.95, v, nv, r, done, term, eps=1e-4)
+
+    big, mid, small = batch(65536, 1), batch(8192, 2), batch(256, 3)   # grids of 256, 64 and 32 blocks on 256 CUs
+    want = {}
+    for name, fn in (("big", big), ("mid", mid), ("small", small)):
+        want[name] = fn()
+        assert F.last_kernel() == "gae_fused"
+    for _ in range(2):
+        for k in range(255):
+            out = small() if k % 5 else mid()
+        assert torch.equal(out[0], want["small"][0])
+        got = big()
+        assert torch.equal(got[0], want["big"][0]) and torch.equal(got[1], want["big"][1])
+    for name, fn in (("mid", mid), ("small", small), ("big", big)):
+        got = fn()
+        assert torch.equal(got[0], want[name][0]) and torch.equal(got[1], want[name][1])
+    torch.cuda.synchronize()
+    assert not F.workspace_error() and not F.fused_degraded()

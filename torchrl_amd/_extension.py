@@ -19,7 +19,7 @@ import warnings
 _LIB_NAME = "libtrl_value.so"
 # TRL_VALUE_LIB: development switch (kernel variants built beside the product library); unset in normal use
 _LIB_PATH = os.environ.get("TRL_VALUE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", _LIB_NAME)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 EXTENSION_WARNING = (
     f"Failed to load the torchrl_amd HIP library ({_LIB_PATH}). The value estimators "

@@ -61,6 +61,7 @@ struct FusedGeom {
     double n_total;
     double eps;
     unsigned *host_flag;  // device view of the library's pinned host word (may be null): raised when a launch gives up
+    int slot_stride;      // granules per replica in the workspace = the largest grid a launch on it uses (>= gridDim.x)
 };
 
 // FULL: every team's K chunks are complete (nchunks == K * grid * kTeams, whole chunks of 256*V elements, aligned):
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(kFusedThreads) void gae_fused_kernel(typename Op::A
             bss += red[2 * k + 1];
         }
         double acc, tot_ss;
-        const bool all_ok = gather::publish_and_gather(ws->slots, kSlotReplicas, (int)gridDim.x, (int)blockIdx.x, tag, lane, bs, bss, acc, tot_ss);
+        const bool all_ok = gather::publish_and_gather(ws->slots, kSlotReplicas, geo.slot_stride, (int)gridDim.x, (int)blockIdx.x, tag, lane,
+                                                       bs, bss, acc, tot_ss);
         double tot_n = geo.n_total;
         bool x_ok = true;
         if constexpr (XCHG) {
@@ -198,6 +200,10 @@ __global__ __launch_bounds__(kFusedThreads) void gae_fused_kernel(typename Op::A
                 }
             }
         }
+    }
+    else if (wv == 1 && geo.slot_stride > (int)gridDim.x) {
+        // a grid smaller than the workspace's layout (small batches, below): keep the absent blocks' slots one launch fresh
+        gather::refresh_absent_slots(ws->slots, kSlotReplicas, geo.slot_stride, (int)gridDim.x, (int)blockIdx.x, tag, lane);
     }
     __syncthreads();
     const TS mean_s = bc_ms[0], std_s = bc_ms[1];
@@ -263,6 +269,15 @@ LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *w
     if (R >= q) R -= R % q;
     if (R > a.O) R = a.O;
     const i64 nchunks = (a.O + R - 1) / R;
+    // Batches of fewer chunks than team slots (the [65536 / N x 32] shards of a batch on N >= 4 GPUs, minibatches): one chunk
+    // per team on a SMALLER grid -- fewer blocks to dispatch, fewer granules to gather, and the FULL specialisation applies
+    // again.  Measured (graph replay, us per step, grid 256 / 128 / 64 / 32): [16384x32] 6.14 / 5.45 / 6.81 / 9.71, [8192x32]
+    // 6.14 / 5.92 / 5.31 / 6.89, [4096x32] 6.22 / 5.93 / 5.79 / 5.40; with two or more chunks per team the full grid wins
+    // ([32768x32]: 5.80 / 6.98).  The slot layout keeps the full grid's stride and the absent blocks' slots are refreshed.
+    const int slot_stride = G;
+    constexpr int kMinGrid = 32;
+    const i64 blocks_wanted = (nchunks + kTeams - 1) / kTeams;
+    if (blocks_wanted < G) G = (int)(blocks_wanted > kMinGrid ? blocks_wanted : (G < kMinGrid ? G : kMinGrid));
     const i64 per_iter = (i64)G * kTeams;
     const i64 k_needed = (nchunks + per_iter - 1) / per_iter;
     // the advantages of K chunks stay in registers: K = 8 fits the 128 VGPRs of a 1024-thread block except for fp32 values
@@ -277,7 +292,7 @@ LaunchResult launch_fused_t(hipStream_t s, const GaeArgs &a, double eps, void *w
     const int KK = k_needed <= 1 ? 1 : k_needed <= 2 ? 2 : k_needed <= 4 ? 4 : 8;
     // every team's KK chunks complete: whole chunks (R*T == 256*V), all rows used, exactly KK chunks per team
     const bool full = vec && R * a.T == chunk && a.O % R == 0 && nchunks == (i64)KK * per_iter;
-    FusedGeom geo{a.O, a.T, (int)R, scan_lanes_for(a.T, V, wi), nchunks, (double)a.O * (double)a.T, eps, host_flag};
+    FusedGeom geo{a.O, a.T, (int)R, scan_lanes_for(a.T, V, wi), nchunks, (double)a.O * (double)a.T, eps, host_flag, slot_stride};
     const dim3 grid((unsigned)G);
     FusedWs *w = (FusedWs *)ws;
     const bool x = xd.local != nullptr;

@@ -11,8 +11,8 @@
 // Measured at C4 (tools/kbench/kfused3.hip, kxchg.hip): 1 / 4 / 8 / 16 / 32 replicas 7.81 / 7.48 / 7.45 / 7.49 / 7.58 us per
 // launch; one 128-byte line per block polled with 8-byte loads (round 2) 7.95; line strides of 256 B - 16 KB no better;
 // two-level gathers (16 x 16, 8 x 32 groups) 7.5 - 7.7; two poll rounds in flight: slower.
-// Rule for the callers: EVERY slot a launch may read is rewritten by that launch (same grid, same slot set, every time):
-// a stale tag can then be at most one launch old and never matches.
+// Rule for the callers: EVERY slot of the workspace is rewritten by EVERY launch (by the block that owns it, or -- grids
+// smaller than the layout's stride -- by refresh_absent_slots): a stale tag is then at most one launch old and never matches.
 #pragma once
 #include "common.h"
 
@@ -58,16 +58,18 @@ __device__ __forceinline__ unsigned long long tag_bits(double x, unsigned tag) {
 }
 __device__ __forceinline__ double untag(unsigned long long b) { return __longlong_as_double((long long)(b & ~0xffull)); }
 
-// Called by ONE whole wave of every block of the grid.  `slots`: nrep packed arrays of nblocks granules (nrep <= 64).
-// Publishes {bs, bss} as block `block`'s granule in every replica, sweeps replica block % nrep until all nblocks tags match
-// and returns the sums over the blocks (wave-uniform, fixed order); false if it gave up after 1 s.
-__device__ __forceinline__ bool publish_and_gather(unsigned long long *slots, int nrep, int nblocks, int block, unsigned tag, int lane,
-                                                   double bs, double bss, double &tot, double &tot2) {
+// Called by ONE whole wave of every block of the grid.  `slots`: nrep packed arrays of `stride` granules each (nrep <= 64),
+// of which this launch uses the first nblocks (stride = the largest grid any launch on this workspace uses: the layout
+// does not depend on the grid).  Publishes {bs, bss} as block `block`'s granule in every replica, sweeps replica
+// block % nrep until all nblocks tags match and returns the sums over the blocks (wave-uniform, fixed order); false if it
+// gave up after 1 s.
+__device__ __forceinline__ bool publish_and_gather(unsigned long long *slots, int nrep, int stride, int nblocks, int block, unsigned tag,
+                                                   int lane, double bs, double bss, double &tot, double &tot2) {
     __builtin_amdgcn_s_setprio(3);  // the publish and the polls go ahead of the other waves' traffic (8.25 -> 8.18 us at C4)
-    if (lane < nrep) store_granule(slots + ((size_t)lane * nblocks + block) * 2, tag_bits(bs, tag), tag_bits(bss, tag));
+    if (lane < nrep) store_granule(slots + ((size_t)lane * stride + block) * 2, tag_bits(bs, tag), tag_bits(bss, tag));
     // lane l gathers blocks l, l + 64, ... of its replica: every round re-reads the whole array (re-polling only the missing
     // granules saves nothing on coalesced loads)
-    const unsigned long long *rep = slots + (size_t)(block % nrep) * nblocks * 2;
+    const unsigned long long *rep = slots + (size_t)(block % nrep) * stride * 2;
     const int i0 = lane, i1 = lane + 64, i2 = lane + 128, i3 = lane + 192;
     auto at = [&](int i) { return rep + (size_t)(i < nblocks ? i : nblocks - 1) * 2; };  // lanes past the grid re-read the last granule
     u64x2 v[8] = {};
@@ -87,7 +89,7 @@ __device__ __forceinline__ bool publish_and_gather(unsigned long long *slots, in
     __builtin_amdgcn_s_setprio(0);
     const bool all_ok = __all(ok);
     if (!all_ok && lane < nrep)  // nothing this block published may match the NEXT launch's tag
-        store_granule(slots + ((size_t)lane * nblocks + block) * 2, tag_bits(bs, (tag - 1u) & 0xffu), tag_bits(bss, (tag - 1u) & 0xffu));
+        store_granule(slots + ((size_t)lane * stride + block) * 2, tag_bits(bs, (tag - 1u) & 0xffu), tag_bits(bss, (tag - 1u) & 0xffu));
     double acc = 0.0, acq = 0.0;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -95,6 +97,23 @@ __device__ __forceinline__ bool publish_and_gather(unsigned long long *slots, in
     tot = wave_sum(acc);
     tot2 = wave_sum(acq);
     return all_ok;
+}
+
+// A launch whose grid is smaller than `stride` keeps the slots of the absent blocks [nblocks, stride) one launch fresh (the
+// rule above) -- with the PREVIOUS tag: nobody reads them in this launch and they can never match the next one, whatever tag
+// this block computed.  Called by one whole wave of every block that is not the gathering wave (off the critical path).
+__device__ __forceinline__ void refresh_absent_slots(unsigned long long *slots, int nrep, int stride, int nblocks, int block, unsigned tag,
+                                                     int lane) {
+    const int absent = (stride - nblocks) * nrep;                  // (replica, block) pairs nobody writes in this launch
+    const int per = (absent + nblocks - 1) / nblocks;              // ... dealt evenly to the blocks that exist
+    const unsigned old = (tag - 1u) & 0xffu;
+    for (int k = lane; k < per; k += kWave) {
+        const int idx = block * per + k;
+        if (idx < absent) {
+            const int rep = idx / (stride - nblocks), b = nblocks + idx % (stride - nblocks);
+            store_granule(slots + ((size_t)rep * stride + b) * 2, tag_bits(0.0, old), tag_bits(0.0, old));
+        }
+    }
 }
 
 }  // namespace gather

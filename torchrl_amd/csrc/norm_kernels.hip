@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kPnThreads) void standardize_persistent_kernel(cons
         unsigned long long *slots = ws->slots + (size_t)wv * geo.nrep * nb * 2;
         if (mine) {
             double tot, tot2;
-            const bool ok = gather::publish_and_gather(slots, geo.nrep, nb, (int)blockIdx.x, tag, lane, bs, bss, tot, tot2);
+            const bool ok = gather::publish_and_gather(slots, geo.nrep, nb, nb, (int)blockIdx.x, tag, lane, bs, bss, tot, tot2);
             if (lane == 0) {
                 TS mean_s = (TS)0, std_s = (TS)1;  // a launch that gave up leaves x un-normalised
                 if (ok) mean_std<TS>(geo.m_count, tot, tot2, geo.eps, mean_s, std_s);
