@@ -44,14 +44,15 @@ KERNEL_BATCHES, KERNEL_BATCH = 5, 200   # kernel_ms = median over 5 batches of 2
 COLD_SETS = 10             # cold leg: rotate over 10 distinct input / output buffer sets, 461 MB > the 256 MiB Infinity Cache
 
 
-def pmc_traffic(kernel_name):
+def pmc_traffic(kernel_name, cold=False):
     """HBM bytes per launch of the fused kernel from the PMC counters: the newest profiles/r*_pmc_hbm_traffic.json
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 as the guide prescribes for gfx950;
     tools/profile_bench.sh + tools/summarize_pmc.py).  A counter pass cannot run inside the timed bench, so the measured
     figure of the committed profile is carried; None when there is none for this kernel."""
     if kernel_name != "gae_fused":
         return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json"))
+                   if ("_cold_" in os.path.basename(f)) == cold)   # the cold leg has its own counter passes (--cold-only)
     for f in reversed(files):
         try:
             with open(f) as fh:
@@ -437,7 +438,8 @@ def main():
         copy_gbs = 8 * n_copy / (device_ms(lambda: dst.copy_(src), 10) * 1e-3) / 1e9
         del src, dst
         cold_bytes = O_ENVS * T_STEPS * BYTES_PER_TRANSITION
-        cold = {"kernel_ms": cold_ms, "kernel_ms_batches": cold_batches, "achieved": cold_bytes / (cold_ms * 1e-3) / 1e9,
+        cold_traffic, cold_traffic_src = pmc_traffic("gae_fused", cold=True)
+        cold = {"traffic": cold_traffic, "traffic_source": cold_traffic_src, "kernel_ms": cold_ms, "kernel_ms_batches": cold_batches, "achieved": cold_bytes / (cold_ms * 1e-3) / 1e9,
                 "frac": cold_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "buffer_sets": COLD_SETS,
                 "footprint_bytes": COLD_SETS * O_ENVS * T_STEPS * BYTES_PER_TRANSITION,
                 "copy_ceiling_gbs": copy_gbs, "frac_of_copy_ceiling": cold_bytes / (cold_ms * 1e-3) / 1e9 / copy_gbs,
