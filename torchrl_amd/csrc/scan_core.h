@@ -249,6 +249,9 @@ struct GaeOp {
     static constexpr bool kShifted = false;  // see Shifted<> below
     static constexpr bool kReversed = false;    // see the adjoint ops (bwd_ops.h)
     static constexpr bool kCustomEmit = false;
+    // look-back kernel (scan_impl.h): two 1024-thread blocks per CU (8 waves per SIMD) when the op fits 64 VGPRs (fp32: 70
+    // without the hint)
+    static constexpr int kLbWavesPerSimd = (sizeof(TS_) == 4 && sizeof(TG_) == 4) ? 8 : 1;
     struct Raw {
         TS r[V], v[V], nv[V];
         u8 d[V], tm[V];

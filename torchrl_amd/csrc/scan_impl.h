@@ -393,8 +393,16 @@ __device__ __forceinline__ unsigned long long lb_load(const unsigned long long *
 
 constexpr int kLbTeams = 4;  // teams per look-back block: one ticket / one record per 4 * 256 * V steps
 
+// waves per SIMD an op asks the look-back kernel to be compiled for (Op::kLbWavesPerSimd; default: no constraint): a look-back
+// block spends most of its life waiting -- for its loads, then for its successors' records -- so a second resident
+// 1024-thread block per CU (8 waves per SIMD, <= 64 VGPRs) overlaps those waits
+template <class Op, class = void>
+struct LbWavesPerSimd { static constexpr int value = 1; };
+template <class Op>
+struct LbWavesPerSimd<Op, std::void_t<decltype(Op::kLbWavesPerSimd)>> { static constexpr int value = Op::kLbWavesPerSimd; };
+
 template <class Op, bool VEC>
-__global__ __launch_bounds__(kLbTeams * kTeam) void scan_lookback_kernel(typename Op::Args args, ScanGeom geo, LbHeader *hdr,
+__global__ __launch_bounds__(kLbTeams * kTeam, LbWavesPerSimd<Op>::value) void scan_lookback_kernel(typename Op::Args args, ScanGeom geo, LbHeader *hdr,
                                                                         LbRecord *rec) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
