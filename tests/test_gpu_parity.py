@@ -441,7 +441,10 @@ def test_broadcast_masks_read_in_place(shape, time_dim, dtype):
 
 LONG_IL = [((16, 400, 5), -2), ((3, 2000, 3, 2), 1), ((64, 1000, 5, 1), -3), ((5, 300, 4), -2), ((7, 257, 2), -2), ((2, 5000, 8), -2),
            ((300, 256, 7), -2), ((40, 700, 12), -2), ((6, 300, 9), -2), ((3, 130, 4, 4), 1), ((5, 260, 17), -2), ((2, 600, 31), -2),
-           ((70, 40, 31), -2), ((1100, 300, 3), -2)]
+           ((70, 40, 31), -2), ((1100, 300, 3), -2),
+           # I = G * NI with the G groups of a step in neighbouring lanes (round 3): short rows (T <= 256 / G) and long ones
+           ((50, 40, 16), -2), ((20, 300, 24), -2), ((64, 20, 10), -2), ((9, 70, 20), -2), ((5, 33, 28), -2), ((33, 129, 14), -2),
+           ((300, 64, 16), -2), ((3, 1000, 16), -2)]
 
 
 @pytest.mark.parametrize("shape", [(16, 400, 5), (40, 700, 12)], ids=["16x400x5", "40x700x12"])

@@ -156,8 +156,13 @@ static bool prefer_lockstep(int val_dtype, int coef_dtype, int64_t T, int64_t I)
 // Outer rows too long for the transposing kernel, 9 <= I <= 31: lock-step groups or the SEQ walk (coalesced only
 // over i, but every (o, i) row is a lane).  Measured fp32 (SEQ / LOCKSTEP us): [64x1000x16] 381 / 20, [1024x300x16]
 // 145 / 62, [4096x300x16] 281 / 218, [1024x100x31] 68 / 65, [8192x100x16] 117 / 146, [16384x64x31] 360 / 817:
-// SEQ once there are enough rows to hide its per-step latency.
-static bool lockstep_over_seq(int64_t O, int64_t I) { return I <= 8 || O * I < 131072; }
+// SEQ once there are enough rows to hide its per-step latency -- unless I factors as G * NI (G = 2 / 4 / 8 groups of a step
+// in neighbouring lanes, lockstep_impl.h, round 3): then a wave reads whole cache lines and LOCKSTEP wins everywhere
+// measured ([8192x100x16] 129 / 55, [16384x64x20] 207 / 149, [8192x100x24] 193 / 163, [4096x300x16] 281 / 82).
+static bool lockstep_over_seq(int64_t O, int64_t I) {
+    const bool lanes = I == 10 || I == 12 || I == 14 || I == 16 || I == 20 || I == 24 || I == 28;
+    return I <= 8 || lanes || O * I < 131072;
+}
 
 // error reporting for the other translation units' entry points (xchg_kernels.hip)
 int trl_internal_fail(int code, const char *fmt, ...) {

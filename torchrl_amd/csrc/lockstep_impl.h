@@ -35,24 +35,28 @@ struct LsGeom {
     i64 nchunks;         // short rows: chunks in total; long rows: chunks per row
 };
 
-template <class Op, int NW>
+// G: groups of a step that sit in NEIGHBOURING LANES (1: a lane owns a whole step, or the groups are on blockIdx.y)
+template <class Op, int NW, int G>
 struct LsShared {
-    typename Op::TC a[2][NW][Op::V], b[2][NW][Op::V];
-    int h[2][NW];
-    typename Op::TS v0[2][NW][Op::V];
+    typename Op::TC a[2][NW][G][Op::V], b[2][NW][G][Op::V];
+    int h[2][NW][G];
+    typename Op::TS v0[2][NW][G][Op::V];
 };
 
 // One chunk: lane = one time step (valid or not), op prepared with the step's I elements.
 // Xc / Xv (in/out, block-uniform): x / state_value of the step that follows the chunk, per feature element; on exit those
 // of the chunk's first step.
-template <class Op, int NW, class Emit>
-__device__ __forceinline__ void ls_chunk(const Op &op, LsShared<Op, NW> &sh, int buf, bool valid, bool row_end,
+// G > 1 (a power of two): lane l holds group l % G of step l / G -- the step that follows a lane's is G lanes further, so
+// the scan moves by G, 2G, ... lanes and the G groups of a wave keep separate aggregates and carries.
+template <class Op, int NW, int G, class Emit>
+__device__ __forceinline__ void ls_chunk(const Op &op, LsShared<Op, NW, G> &sh, int buf, bool valid, bool row_end,
                                          typename Op::TC (&Xc)[Op::V], typename Op::TS (&Xv)[Op::V], Emit &&emit) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
     constexpr int NI = Op::V;
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8, "groups per step in neighbouring lanes: a power of two below 16");
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-    const int lir = lane & 15, row = lane >> 4;
+    const int lir = lane & 15, row = lane >> 4, gl = lane & (G - 1);
 
     // The hard-reset flag of a map says "a row end lies in the range": it is a property of the LANES covered, the same
     // for the I maps of a lane -- one register and one move per scan step instead of I.
@@ -79,28 +83,35 @@ __device__ __forceinline__ void ls_chunk(const Op &op, LsShared<Op, NW> &sh, int
         if (COND) Sh |= ph_;                                              \
     }
     // inclusive suffix scan over the wave, I maps per move
-    TRL_LS_COMPOSE(lir + 1 < 16, dpp_mov<0x101>(Sa[e]), dpp_mov<0x101>(Sb[e]), dpp_mov<0x101>(Sh))
-    TRL_LS_COMPOSE(lir + 2 < 16, dpp_mov<0x102>(Sa[e]), dpp_mov<0x102>(Sb[e]), dpp_mov<0x102>(Sh))
-    TRL_LS_COMPOSE(lir + 4 < 16, dpp_mov<0x104>(Sa[e]), dpp_mov<0x104>(Sb[e]), dpp_mov<0x104>(Sh))
+    if constexpr (G <= 1) TRL_LS_COMPOSE(lir + 1 < 16, dpp_mov<0x101>(Sa[e]), dpp_mov<0x101>(Sb[e]), dpp_mov<0x101>(Sh))
+    if constexpr (G <= 2) TRL_LS_COMPOSE(lir + 2 < 16, dpp_mov<0x102>(Sa[e]), dpp_mov<0x102>(Sb[e]), dpp_mov<0x102>(Sh))
+    if constexpr (G <= 4) TRL_LS_COMPOSE(lir + 4 < 16, dpp_mov<0x104>(Sa[e]), dpp_mov<0x104>(Sb[e]), dpp_mov<0x104>(Sh))
     TRL_LS_COMPOSE(lir + 8 < 16, dpp_mov<0x108>(Sa[e]), dpp_mov<0x108>(Sb[e]), dpp_mov<0x108>(Sh))
-    TRL_LS_COMPOSE((row & 1) == 0, __shfl(Sa[e], (row + 1) << 4, kWave), __shfl(Sb[e], (row + 1) << 4, kWave), __shfl(Sh, (row + 1) << 4, kWave))
-    TRL_LS_COMPOSE(row < 2, __shfl(Sa[e], 32, kWave), __shfl(Sb[e], 32, kWave), __shfl(Sh, 32, kWave))
+    // the 16-lane rows that follow: their totals sit in their first G lanes (one per group)
+    TRL_LS_COMPOSE((row & 1) == 0, __shfl(Sa[e], ((row + 1) << 4) + gl, kWave), __shfl(Sb[e], ((row + 1) << 4) + gl, kWave),
+                   __shfl(Sh, ((row + 1) << 4) + gl, kWave))
+    TRL_LS_COMPOSE(row < 2, __shfl(Sa[e], 32 + gl, kWave), __shfl(Sb[e], 32 + gl, kWave), __shfl(Sh, 32 + gl, kWave))
 #undef TRL_LS_COMPOSE
-    if (lane == 0) {
-        sh.h[buf][w] = Sh;
+    if (lane < G) {
+        sh.h[buf][w][gl] = Sh;
 #pragma unroll
         for (int e = 0; e < NI; ++e) {
-            sh.a[buf][w][e] = Sa[e];
-            sh.b[buf][w][e] = Sb[e];
-            if (Op::kNeedsNext) sh.v0[buf][w][e] = op.value(e);
+            sh.a[buf][w][gl][e] = Sa[e];
+            sh.b[buf][w][gl][e] = Sb[e];
+            if (Op::kNeedsNext) sh.v0[buf][w][gl][e] = op.value(e);
         }
     }
     __syncthreads();
     TC xs[NI], x_in[NI];
     TS vn[NI];
-    // exclusive map (everything after this lane inside the wave) = the inclusive one of the next lane
-    int Eh = dpp_mov<0x130>(Sh);
-    if (lane == kWave - 1) Eh = 0;
+    // exclusive map (everything after this lane inside the wave) = the inclusive one of the lane that holds the next step
+    auto next_step = [&](auto x) {
+        if constexpr (G == 1) return dpp_mov<0x130>(x);
+        else return __shfl_down(x, G, kWave);
+    };
+    const bool last_in_wave = lane >= kWave - G;
+    int Eh = next_step(Sh);
+    if (last_in_wave) Eh = 0;
 #pragma unroll
     for (int e = 0; e < NI; ++e) {
         // carry into this wave from the waves that follow it and from the chunk's carry-in
@@ -109,15 +120,15 @@ __device__ __forceinline__ void ls_chunk(const Op &op, LsShared<Op, NW> &sh, int
 #pragma unroll
         for (int k = NW - 1; k >= 0; --k) {
             if (k == w) { Cw = x; Cv = xv; }
-            x = apply(Aff<TC>{sh.a[buf][k][e], sh.b[buf][k][e], sh.h[buf][k]}, x);
-            if (Op::kNeedsNext) xv = sh.v0[buf][k][e];
+            x = apply(Aff<TC>{sh.a[buf][k][gl][e], sh.b[buf][k][gl][e], sh.h[buf][k][gl]}, x);
+            if (Op::kNeedsNext) xv = sh.v0[buf][k][gl][e];
         }
         Xc[e] = x;
         Xv[e] = xv;
-        Aff<TC> E{dpp_mov<0x130>(Sa[e]), dpp_mov<0x130>(Sb[e]), Eh};
-        if (lane == kWave - 1) E = Aff<TC>{(TC)1, (TC)0, 0};
-        vn[e] = Op::kNeedsNext ? dpp_mov<0x130>(op.value(e)) : (TS)0;
-        if (Op::kNeedsNext && lane == kWave - 1) vn[e] = Cv;
+        Aff<TC> E{next_step(Sa[e]), next_step(Sb[e]), Eh};
+        if (last_in_wave) E = Aff<TC>{(TC)1, (TC)0, 0};
+        vn[e] = Op::kNeedsNext ? next_step(op.value(e)) : (TS)0;
+        if (Op::kNeedsNext && last_in_wave) vn[e] = Cv;
         x_in[e] = apply(E, Cw);
         xs[e] = op.step(e, row_end ? op.init(e) : x_in[e]);  // the reference's exact step from the carry-in
     }
@@ -154,25 +165,30 @@ constexpr int ls_waves() {
     return Op::V <= 3 ? 5 : Op::V <= 5 ? 4 : 3;
 }
 
-template <class Op, bool VEC, int NT>
+// G > 1: the I = G * NI feature elements of a step are held by G neighbouring lanes (a block covers NT / G steps), so a
+// wave reads 64 * NI CONSECUTIVE elements per tensor -- whole cache lines -- instead of NI of every I (blockIdx.y groups:
+// every group's blocks fetch the same lines at different times; [4096x300x16] ran at 2 TB/s).
+template <class Op, bool VEC, int NT, int G>
 __global__ __launch_bounds__(NT, ls_waves<Op>()) void lockstep_kernel(typename Op::Args args, LsGeom geo, double *partials) {
     typedef typename Op::TC TC;
     typedef typename Op::TS TS;
     typedef typename Op::TO TO;
     constexpr int NI = Op::V;
     constexpr int NW = NT / kWave;
-    __shared__ LsShared<Op, NW> sh;
+    constexpr int NS = NT / G;  // steps per chunk
+    __shared__ LsShared<Op, NW, G> sh;
     __shared__ double red[2 * NW];
     double s = 0.0, ss = 0.0;
     int buf = 0;
-    const int I = geo.I, i0 = (int)blockIdx.y * NI;
+    const int I = geo.I, i0 = (G > 1 ? (int)(threadIdx.x & (G - 1)) : (int)blockIdx.y) * NI;
     const int ne = I - i0 < NI ? I - i0 : NI;
+    const unsigned slot = threadIdx.x / G;  // the step of the chunk this lane works on
     auto run = [&](i64 step_index, bool valid, bool row_end, TC (&Xc)[NI], TS (&Xv)[NI]) {
         typename Op::Raw raw;
         ls_load<Op, VEC>(args, step_index, I, i0, ne, valid, raw);
         Op op;
         op.prepare(args, raw);
-        ls_chunk<Op, NW>(op, sh, buf, valid, row_end, Xc, Xv, [&](const TC(&xs)[NI], const TC(&x_in)[NI], const TS(&vn)[NI]) {
+        ls_chunk<Op, NW, G>(op, sh, buf, valid, row_end, Xc, Xv, [&](const TC(&xs)[NI], const TC(&x_in)[NI], const TS(&vn)[NI]) {
             TO o0[NI], o1[NI];
             op.outputs_ls(valid, xs, row_end, x_in, vn, o0, o1, s, ss);
             store_n<VEC>(Op::out_ptr(args, 0), step_index * I + i0, valid ? ne : 0, o0);
@@ -183,7 +199,7 @@ __global__ __launch_bounds__(NT, ls_waves<Op>()) void lockstep_kernel(typename O
     if (geo.rows_per_chunk > 0) {
         // short rows: R whole outer rows per chunk, every chunk ends at a row end (no carry between chunks)
         const unsigned T = (unsigned)geo.T;
-        const unsigned lr = threadIdx.x / T, t = threadIdx.x % T;
+        const unsigned lr = slot / T, t = slot % T;
         for (i64 c = blockIdx.x; c < geo.nchunks; c += gridDim.x) {
             const i64 row = c * geo.rows_per_chunk + lr;
             const bool valid = lr < (unsigned)geo.rows_per_chunk && row < geo.O;
@@ -200,7 +216,7 @@ __global__ __launch_bounds__(NT, ls_waves<Op>()) void lockstep_kernel(typename O
 #pragma unroll
             for (int e = 0; e < NI; ++e) { Xc[e] = (TC)0; Xv[e] = (TS)0; }
             for (i64 c = geo.nchunks - 1; c >= 0; --c) {
-                const i64 t = c * NT + threadIdx.x;
+                const i64 t = c * NS + slot;
                 const bool valid = t < geo.T;
                 run(row * geo.T + t, valid, valid && t == geo.T - 1, Xc, Xv);
             }
@@ -221,6 +237,39 @@ int ls_cus() {
     if (hipGetDevice(&dev) != hipSuccess) return 256;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
     return n;
+}
+
+template <template <typename, typename, int> class OpT, typename TS, typename TG, int NI, int NT, class Args>
+LaunchResult launch_ls_nt(hipStream_t s, const Args &a, bool aligned, double *partials, const char *name);
+
+// the groups of a step in neighbouring lanes (I == G * NI): blockIdx.y is not used
+template <template <typename, typename, int> class OpT, typename TS, typename TG, int NI, int G, class Args>
+LaunchResult launch_ls_lanes(hipStream_t s, const Args &a, bool aligned, double *partials, const char *name) {
+    typedef OpT<TS, TG, NI> Op;
+    constexpr int NT = 256, NS = NT / G;
+    static const int cus = ls_cus();
+    LsGeom geo{a.O, a.T, (int)a.I, 0, 0};
+    i64 grid;
+    if (a.T <= NS) {
+        i64 R = NS / a.T;
+        if (R > a.O) R = a.O;
+        geo.rows_per_chunk = (int)R;
+        geo.nchunks = (a.O + R - 1) / R;
+        const i64 cap = (i64)cus * 8;
+        grid = geo.nchunks < cap ? geo.nchunks : cap;
+    } else {
+        geo.nchunks = (a.T + NS - 1) / NS;
+        grid = a.O < 2048 ? a.O : 2048;
+    }
+    const dim3 g((unsigned)grid, 1u);
+    if constexpr (NI == 2 || NI == 4 || NI == 8) {
+        if (aligned) {
+            hipLaunchKernelGGL((lockstep_kernel<Op, true, NT, G>), g, dim3(NT), 0, s, a, geo, partials);
+            return LaunchResult{0, grid, name};
+        }
+    }
+    hipLaunchKernelGGL((lockstep_kernel<Op, false, NT, G>), g, dim3(NT), 0, s, a, geo, partials);
+    return LaunchResult{0, grid, name};
 }
 
 template <template <typename, typename, int> class OpT, typename TS, typename TG, int NI, int NT, class Args>
@@ -249,11 +298,11 @@ LaunchResult launch_ls_nt(hipStream_t s, const Args &a, bool aligned, double *pa
     const dim3 g((unsigned)grid, (unsigned)groups);
     if constexpr (NI == 2 || NI == 4 || NI == 8) {
         if (aligned && a.I % NI == 0) {
-            hipLaunchKernelGGL((lockstep_kernel<Op, true, NT>), g, dim3(NT), 0, s, a, geo, partials);
+            hipLaunchKernelGGL((lockstep_kernel<Op, true, NT, 1>), g, dim3(NT), 0, s, a, geo, partials);
             return LaunchResult{0, grid * groups, name};
         }
     }
-    hipLaunchKernelGGL((lockstep_kernel<Op, false, NT>), g, dim3(NT), 0, s, a, geo, partials);
+    hipLaunchKernelGGL((lockstep_kernel<Op, false, NT, 1>), g, dim3(NT), 0, s, a, geo, partials);
     return LaunchResult{0, grid * groups, name};
 }
 
@@ -273,6 +322,31 @@ LaunchResult launch_ls(hipStream_t s, const Args &a, bool aligned, double *parti
 template <template <typename, typename, int> class OpT, class Args>
 LaunchResult dispatch_ls(hipStream_t s, int vdt, int cdt, const Args &a, bool aligned, double *partials, const char *name) {
     if (a.I < 2 || a.I > 31 || a.T >= (1LL << 31) - 4096) return LaunchResult{2, 0, nullptr};
+    // 9 <= I <= 31 = G * NI with G a power of two and NI <= 8: the G groups of a step in neighbouring lanes (whole cache lines
+    // per wave).  Measured fp32 GAE (round 3), groups on blockIdx.y -> in lanes: [4096x300x16] 218 -> 82 us (5.3 TB/s),
+    // [8192x100x16] 146 -> 55 (SEQ 129), [1024x300x16] 62 -> 22, [256x300x24] 49 -> 22; few small groups beat fewer large
+    // ones (registers): I = 12 as 4 x 3 107 us vs 2 x 6 124 at [4096x300x12], I = 24 as 8 x 3 183 vs 4 x 6 225 at
+    // [4096x300x24].  A handful of long rows keeps the old mapping (more blocks: [64x1000x16] 20 vs 29 us).
+    if (a.I > 8 && (a.T <= 32 || a.O >= 128)) {
+#define TRL_LS_LANES(G_, N_)                                                                                              \
+    do {                                                                                                                  \
+        if (vdt == 0 && cdt == 0) return launch_ls_lanes<OpT, float, float, N_, G_>(s, a, aligned, partials, name);        \
+        if (vdt == 0) return launch_ls_lanes<OpT, float, double, N_, G_>(s, a, aligned, partials, name);                   \
+        if (cdt == 1) return launch_ls_lanes<OpT, double, double, N_, G_>(s, a, aligned, partials, name);                  \
+        return launch_ls_lanes<OpT, double, float, N_, G_>(s, a, aligned, partials, name);                                 \
+    } while (0)
+        switch ((int)a.I) {
+            case 10: TRL_LS_LANES(2, 5);
+            case 12: TRL_LS_LANES(4, 3);
+            case 14: TRL_LS_LANES(2, 7);
+            case 16: TRL_LS_LANES(4, 4);
+            case 20: TRL_LS_LANES(4, 5);
+            case 24: TRL_LS_LANES(8, 3);
+            case 28: TRL_LS_LANES(4, 7);
+            default: break;  // no such factorisation: groups on blockIdx.y, below
+        }
+#undef TRL_LS_LANES
+    }
     // groups of 8 or 4 when they divide I (full groups, vector loads), else balanced: 9 -> 5 + 4, 31 -> 8 + 8 + 8 + 7
     const int groups = ((int)a.I + 7) / 8;
     const int ni = a.I <= 8 ? (int)a.I : a.I % 8 == 0 ? 8 : a.I % 4 == 0 ? 4 : ((int)a.I + groups - 1) / groups;
