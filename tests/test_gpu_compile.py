@@ -100,3 +100,38 @@ def test_compiled_nonrolling_td_gradients_match_eager():
         grads.append([nv.grad.clone(), r.grad.clone()])
     for a, b in zip(*grads):
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("form", ["full", "zero_dim", "per_step"])
+def test_compiled_gradients_to_coefficient_tensors_match_eager(form):
+    """gamma / lmbda tensors that require grad under torch.compile (round 3; eager-only before): GAE, TD(lambda) with rolling
+    gamma, V-trace's gamma -- full-shape, 0-dim and broadcast ([T, 1]) leaves."""
+    shape = (6, 40, 1)
+
+    def leaves(seed):
+        g = torch.Generator().manual_seed(seed)
+        if form == "full":
+            mk = lambda lo: (lo + 0.09 * torch.rand(shape, generator=g)).to(DEV).requires_grad_(True)
+        elif form == "zero_dim":
+            mk = lambda lo: torch.tensor(lo + 0.05, device=DEV, requires_grad=True)
+        else:
+            mk = lambda lo: (lo + 0.09 * torch.rand(shape[1:], generator=g)).to(DEV).requires_grad_(True)
+        return mk(0.9), mk(0.85)
+
+    def loss(v, nv, r, done, term, lp, lmu, gam, lam):
+        adv, vt = F.generalized_advantage_estimate(gam, lam, v, nv, r, done, term)
+        a, vs = F.vtrace_advantage_estimate(gam, lp, lmu, v, nv, r, done, term)
+        out = (adv * vt).sum() + (a * vs).sum()
+        if form != "per_step":  # the loop variant of TD(lambda) takes scalars or tensors of the inputs' shape only (as the reference)
+            out = out + F.td_lambda_return_estimate(gam, lam, nv, r, done, term).pow(2).sum()
+        return out
+
+    grads = []
+    for fn in (loss, torch.compile(loss, fullgraph=True)):
+        r, v, nv, done, term, lp, lmu = _inputs(shape, seed=6, grad=True)
+        gam, lam = leaves(7)
+        fn(v, nv, r, done, term, lp, lmu, gam, lam).backward()
+        grads.append([t.grad.clone() for t in (gam, lam, v, nv, r, lp)])
+    for a, b in zip(*grads):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-5)

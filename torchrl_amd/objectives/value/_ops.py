@@ -7,8 +7,10 @@ the eager entry points call the library directly -- the dispatcher's per-call co
 
 Each op's implementation is the eager entry point itself (ctypes underneath); ``register_autograd`` wires the backward
 kernels (``trl_gae_bwd`` / ``trl_td_lambda_bwd`` / ``trl_td1_bwd`` / ``trl_vtrace_bwd``) for the value / reward /
-log-probability inputs.  Gradients w.r.t. gamma / lmbda TENSORS are an eager-only feature (compiled graphs treat the
-coefficients as constants).
+log-probability inputs.  Gradients w.r.t. gamma / lmbda TENSORS (round 3): GAE, TD(lambda) with rolling gamma and V-trace's
+gamma -- the tensor enters the op as a differentiable view of the inputs' shape (``_split_leaf``) and the backward forms its
+per-element gradient with torch ops on the kernel's adjoint, as the eager Functions do; TD(1) and the
+``rolling_gamma=False`` forms keep coefficient gradients eager-only.
 """
 from __future__ import annotations
 
@@ -31,6 +33,46 @@ def _split(x):
     if isinstance(x, torch.Tensor):
         return 0.0, x
     return float(x), None
+
+
+def _split_leaf(x, shape, time_dim):
+    """:func:`_split` for a coefficient that may require grad: such a tensor enters the op as a differentiable view of the
+    inputs' shape (traced torch ops, outside the opaque op -- autograd then sums the op's per-element gradient back over the
+    broadcast dims, exactly as for the eager Functions' ``_coef_leaf``)."""
+    if isinstance(x, torch.Tensor) and x.requires_grad and torch.is_grad_enabled():
+        return 0.0, F._coef_leaf(x, tuple(shape), time_dim)
+    return _split(x)
+
+
+def _dims3(shape, time_dim):
+    nd = len(shape)
+    td = time_dim + nd if time_dim < 0 else time_dim
+    O = 1
+    for k in shape[:td]:
+        O *= k
+    I = 1
+    for k in shape[td + 1:]:
+        I *= k
+    return O, shape[td], I
+
+
+def _coef3(scalar, tensor, shape, time_dim, dt, dev):
+    """Detached value of a coefficient in dtype ``dt``: 0-dim, or the canonical (O, T, I) view."""
+    if tensor is None:
+        return torch.full((), scalar, dtype=dt, device=dev)
+    t = tensor.detach().to(device=dev, dtype=dt)
+    if t.numel() == 1:
+        return t.reshape(())
+    t = t if tuple(t.shape) == tuple(shape) else F._expand_coef(t, tuple(shape), time_dim)
+    return t.reshape(_dims3(shape, time_dim))
+
+
+def _leaf_grad(g3, leaf):
+    """Per-element gradient (O, T, I) -> the coefficient tensor's shape (full shape: what _split_leaf hands the op)."""
+    if leaf.numel() != g3.numel():
+        raise NotImplementedError("compiled gradient w.r.t. a broadcast coefficient tensor: pass it through the public functions "
+                                  "(they expand it to the inputs' shape outside the op)")
+    return g3.reshape(leaf.shape).to(leaf.dtype)
 
 
 def _promote_out(*xs):
@@ -71,20 +113,39 @@ def _(g_adv, g_vt, like, done, terminated, gamma, lmbda, gamma_t, lmbda_t, time_
 
 def _gae_setup(ctx, inputs, output):
     state_value, next_state_value, reward, done, terminated, gamma, lmbda, gamma_t, lmbda_t, time_dim, vec = inputs
-    ctx.save_for_backward(done, terminated, gamma_t, lmbda_t)
+    need = ctx.needs_input_grad
+    ctx.coef_grads = (gamma_t is not None and need[7], lmbda_t is not None and need[8])
+    if any(ctx.coef_grads):   # gradients w.r.t. gamma / lmbda tensors: torch ops on the kernel's adjoint (as the eager Function)
+        ctx.save_for_backward(done, terminated, gamma_t, lmbda_t, output[0], next_state_value)
+    else:
+        ctx.save_for_backward(done, terminated, gamma_t, lmbda_t)
     ctx.cfg = (gamma, lmbda, time_dim)
     ctx.like = (reward.shape, F._check_value_dtype(reward, state_value, next_state_value), reward.device)
     ctx.dtypes = (state_value.dtype, next_state_value.dtype, reward.dtype)
 
 
 def _gae_backward(ctx, g_adv, g_vt):
-    done, terminated, gamma_t, lmbda_t = ctx.saved_tensors
+    done, terminated, gamma_t, lmbda_t = ctx.saved_tensors[:4]
     gamma, lmbda, time_dim = ctx.cfg
     shape, dt, dev = ctx.like
     like = torch.empty(shape, dtype=dt, device=dev)
     z = lambda g: torch.zeros(shape, dtype=dt, device=dev) if g is None else g.to(dt)
     d_v, d_nv, d_r = gae_bwd_op(z(g_adv), z(g_vt), like, done, terminated, gamma, lmbda, gamma_t, lmbda_t, time_dim)
-    return (d_v.to(ctx.dtypes[0]), d_nv.to(ctx.dtypes[1]), d_r.to(ctx.dtypes[2]), None, None, None, None, None, None, None, None)
+    d_gamma = d_lmbda = None
+    if any(ctx.coef_grads):
+        # A_t = delta_t + (lmbda_t gamma_t (1 - done_t)) A_{t+1},  delta_t = r_t + gamma_t (1 - terminated_t) v'_t - v_t
+        adv, nv = ctx.saved_tensors[4:6]
+        shp3 = _dims3(shape, time_dim)
+        cdt = _promote_out(like, gamma_t, lmbda_t)
+        A, G = adv.reshape(shp3).to(cdt), d_r.reshape(shp3).to(cdt)
+        nd = (~done).reshape(shp3).to(cdt)
+        nt = (~terminated).reshape(shp3).to(cdt)
+        d_lg = G * nd * F._next_in_time(A, torch.zeros((), dtype=cdt, device=dev))
+        if ctx.coef_grads[0]:
+            d_gamma = _leaf_grad(G * nt * nv.reshape(shp3).to(cdt) + d_lg * _coef3(lmbda, lmbda_t, shape, time_dim, cdt, dev), gamma_t)
+        if ctx.coef_grads[1]:
+            d_lmbda = _leaf_grad(d_lg * _coef3(gamma, gamma_t, shape, time_dim, cdt, dev), lmbda_t)
+    return (d_v.to(ctx.dtypes[0]), d_nv.to(ctx.dtypes[1]), d_r.to(ctx.dtypes[2]), None, None, None, None, d_gamma, d_lmbda, None, None)
 
 
 gae_op.register_autograd(_gae_backward, setup_context=_gae_setup)
@@ -159,8 +220,14 @@ def _(g_ret, next_state_value, reward, done, terminated, gamma, lmbda, gamma_t, 
 def _td_setup(ctx, inputs, output):
     next_state_value, reward, done, terminated, gamma, lmbda, gamma_t, lmbda_t, rolling, time_dim, vec = inputs
     ctx.fixed = rolling == 0 and (gamma_t is not None or lmbda_t is not None)  # rolling_gamma=False: trl_td_fixed_bwd
+    need = ctx.needs_input_grad
+    ctx.coef_grads = (gamma_t is not None and need[6], lmbda_t is not None and need[7])
+    if any(ctx.coef_grads) and ctx.fixed:
+        raise NotImplementedError("compiled gradients w.r.t. gamma / lmbda tensors with rolling_gamma=False: eager mode has them")
     if ctx.fixed:
         ctx.save_for_backward(done, terminated, gamma_t, lmbda_t, next_state_value, reward)
+    elif any(ctx.coef_grads):
+        ctx.save_for_backward(done, terminated, gamma_t, lmbda_t, next_state_value, output)
     else:
         ctx.save_for_backward(done, terminated, gamma_t, lmbda_t)
     ctx.cfg = (gamma, lmbda, time_dim, vec, False)
@@ -175,11 +242,28 @@ def _td_backward(ctx, g_ret):
         d_nv, d_r = td_fixed_bwd_op(g_ret.to(ctx.like[1]), next_state_value, reward, done, terminated, gamma, lmbda, gamma_t, lmbda_t,
                                     time_dim, False)
         return (d_nv.to(ctx.dtypes[0]), d_r.to(ctx.dtypes[1])) + (None,) * 9
-    done, terminated, gamma_t, lmbda_t = ctx.saved_tensors
+    done, terminated, gamma_t, lmbda_t = ctx.saved_tensors[:4]
     shape, dt, dev = ctx.like
     like = torch.empty(shape, dtype=dt, device=dev)
     d_nv, d_r = td_bwd_op(g_ret.to(dt), like, done, terminated, gamma, lmbda, gamma_t, lmbda_t, time_dim, vec, td1)
-    return (d_nv.to(ctx.dtypes[0]), d_r.to(ctx.dtypes[1])) + (None,) * 9
+    d_gamma = d_lmbda = None
+    if any(ctx.coef_grads):
+        # R_t = r_t + gamma_t((1-lmbda_t) v'_t + lmbda_t (g_{t+1} nd_t + v'_t d_t)); g_T := v'_{T-1}  (v' masked by nt)
+        nv, ret = ctx.saved_tensors[4:6]
+        shp3 = _dims3(shape, time_dim)
+        cdt = _promote_out(like, gamma_t, lmbda_t)
+        R, G = ret.reshape(shp3).to(cdt), d_r.reshape(shp3).to(cdt)
+        dn = done.reshape(shp3).to(cdt)
+        nvm = nv.reshape(shp3).to(cdt) * (~terminated).reshape(shp3).to(cdt)
+        # scalar coefficients of TD(lambda) take the value dtype (torch.full_like(next_state_value, gamma))
+        gam = _coef3(F._round_to(gamma, dt), gamma_t, shape, time_dim, cdt, dev)
+        lam = _coef3(F._round_to(lmbda, dt), lmbda_t, shape, time_dim, cdt, dev)
+        g1 = F._next_in_time(R, nvm[:, -1:]) * (1 - dn) + nvm * dn   # what lmbda_t multiplies at step t
+        if ctx.coef_grads[0]:
+            d_gamma = _leaf_grad(G * ((1 - lam) * nvm + lam * g1), gamma_t)
+        if ctx.coef_grads[1]:
+            d_lmbda = _leaf_grad(G * gam * (g1 - nvm), lmbda_t)
+    return (d_nv.to(ctx.dtypes[0]), d_r.to(ctx.dtypes[1]), None, None, None, None, d_gamma, d_lmbda, None, None, None)
 
 
 td_lambda_op.register_autograd(_td_backward, setup_context=_td_setup)
@@ -252,20 +336,22 @@ def _(log_pi, log_mu, state_value, next_state_value, reward, done, terminated, g
 def vtrace_bwd_op(g_adv: Tensor, g_vs: Tensor, vs: Tensor, log_pi: Tensor, log_mu: Tensor, state_value: Tensor, next_state_value: Tensor,
                   reward: Tensor, done: Tensor, terminated: Tensor, gamma: float, gamma_t: Optional[Tensor], rho_thresh: float,
                   c_thresh: float, rho_thresh_t: Optional[Tensor], c_thresh_t: Optional[Tensor],
-                  time_dim: int) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+                  time_dim: int, need_gamma: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
     shape = next_state_value.shape
     full = lambda t: t if tuple(t.shape) == tuple(shape) else F._expand_coef(t, shape, time_dim)
     c = F._prepare_vtrace(_coef(gamma, gamma_t), full(log_pi), full(log_mu), state_value, next_state_value, reward, done, terminated,
                           _coef(rho_thresh, rho_thresh_t), _coef(c_thresh, c_thresh_t), time_dim)
-    outs, _ = F._vtrace_bwd(c, g_adv.reshape(shape), g_vs.reshape(shape), vs, (True,) * 5, False)
-    return tuple(o.view(shape) for o in outs)
+    outs, d_gamma = F._vtrace_bwd(c, g_adv.reshape(shape), g_vs.reshape(shape), vs, (True,) * 5, need_gamma)
+    # the per-element gamma gradient (promoted dtype) comes out of the same launch; an empty tensor when it is not wanted
+    return tuple(o.view(shape) for o in outs) + (d_gamma.view(shape) if need_gamma else vs.new_empty(0),)
 
 
 @vtrace_bwd_op.register_fake
 def _(g_adv, g_vs, vs, log_pi, log_mu, state_value, next_state_value, reward, done, terminated, gamma, gamma_t, rho_thresh, c_thresh,
-      rho_thresh_t, c_thresh_t, time_dim):
+      rho_thresh_t, c_thresh_t, time_dim, need_gamma):
     vdt = F._check_value_dtype(reward, state_value, next_state_value, log_pi, log_mu)
-    return tuple(torch.empty(next_state_value.shape, dtype=vdt, device=next_state_value.device) for _ in range(5))
+    return tuple(torch.empty(next_state_value.shape, dtype=vdt, device=next_state_value.device) for _ in range(5)) + (
+        torch.empty(next_state_value.shape if need_gamma else (0,), dtype=vs.dtype, device=vs.device),)
 
 
 def _vtrace_setup(ctx, inputs, output):
@@ -273,6 +359,7 @@ def _vtrace_setup(ctx, inputs, output):
      c_thresh_t, time_dim) = inputs
     ctx.save_for_backward(output[1], log_pi, log_mu, state_value, next_state_value, reward, done, terminated, gamma_t, rho_thresh_t, c_thresh_t)
     ctx.cfg = (gamma, rho_thresh, c_thresh, time_dim)
+    ctx.need_gamma = gamma_t is not None and ctx.needs_input_grad[8]
 
 
 def _sum_to(g, shape):
@@ -289,9 +376,10 @@ def _vtrace_backward(ctx, g_adv, g_vs):
     if time_dim != -2 and (tuple(log_pi.shape) != tuple(reward.shape) or tuple(log_mu.shape) != tuple(reward.shape)):
         raise NotImplementedError("compiled backward of V-trace with broadcast log-probabilities needs time_dim=-2")
     outs = vtrace_bwd_op(z(g_adv), z(g_vs), vs, log_pi, log_mu, state_value, next_state_value, reward, done, terminated, gamma, gamma_t,
-                         rho_thresh, c_thresh, rho_t, c_t, time_dim)
+                         rho_thresh, c_thresh, rho_t, c_t, time_dim, ctx.need_gamma)
     ins = (log_pi, log_mu, state_value, next_state_value, reward)
-    return tuple(_sum_to(o, t.shape).to(t.dtype) for o, t in zip(outs, ins)) + (None,) * 9
+    d_gamma = _leaf_grad(outs[5], gamma_t) if ctx.need_gamma else None
+    return tuple(_sum_to(o, t.shape).to(t.dtype) for o, t in zip(outs[:5], ins)) + (None, None, None, d_gamma, None, None, None, None, None)
 
 
 vtrace_op.register_autograd(_vtrace_backward, setup_context=_vtrace_setup)

@@ -1074,7 +1074,7 @@ def generalized_advantage_estimate(
     ``[*Batch x TimeSteps x *F]``; ``terminated`` defaults to ``done``.
     """
     if torch.compiler.is_compiling():
-        (g, gt), (l, lt) = _ops._split(gamma), _ops._split(lmbda)
+        (g, gt), (l, lt) = _ops._split_leaf(gamma, next_state_value.shape, time_dim), _ops._split_leaf(lmbda, next_state_value.shape, time_dim)
         return _ops.gae_op(state_value, next_state_value, reward, done, done if terminated is None else terminated, g, l, gt, lt,
                            time_dim, False)
     out = _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, terminated, None, ALGO_AUTO, time_dim)
@@ -1102,7 +1102,7 @@ def vec_generalized_advantage_estimate(
     """Vectorized GAE (reference: functional.py:272-370).  Same kernels as the loop variant:
     the result is exact rather than filter-truncated."""
     if torch.compiler.is_compiling():
-        (g, gt), (l, lt) = _ops._split(gamma), _ops._split(lmbda)
+        (g, gt), (l, lt) = _ops._split_leaf(gamma, next_state_value.shape, time_dim), _ops._split_leaf(lmbda, next_state_value.shape, time_dim)
         return _ops.gae_op(state_value, next_state_value, reward, done, done if terminated is None else terminated, g, l, gt, lt,
                            time_dim, True)
     out = _gae_fast(gamma, lmbda, state_value, next_state_value, reward, done, terminated, None, ALGO_AUTO, time_dim)
@@ -1437,7 +1437,7 @@ def td_lambda_return_estimate(
     whole tail) runs the O(T^2) kernel and needs a gamma or lmbda tensor.
     """
     if torch.compiler.is_compiling():
-        (g, gt), (l, lt) = _ops._split(gamma), _ops._split(lmbda)
+        (g, gt), (l, lt) = _ops._split_leaf(gamma, next_state_value.shape, time_dim), _ops._split_leaf(lmbda, next_state_value.shape, time_dim)
         return _ops.td_lambda_op(next_state_value, reward, done, done if terminated is None else terminated, g, l, gt, lt,
                                  -1 if rolling_gamma is None else int(bool(rolling_gamma)), time_dim, False)
     host = _HOST if _HOST_TRIED else _host_module()
@@ -1468,7 +1468,7 @@ def vec_td_lambda_return_estimate(
     Same kernels as the loop variant; keeps the reference's ``NotImplementedError`` for
     ``rolling_gamma=False`` with tensor coefficients."""
     if torch.compiler.is_compiling():
-        (g, gt), (l, lt) = _ops._split(gamma), _ops._split(lmbda)
+        (g, gt), (l, lt) = _ops._split_leaf(gamma, next_state_value.shape, time_dim), _ops._split_leaf(lmbda, next_state_value.shape, time_dim)
         return _ops.td_lambda_op(next_state_value, reward, done, done if terminated is None else terminated, g, l, gt, lt,
                                  -1 if rolling_gamma is None else int(bool(rolling_gamma)), time_dim, True)
     host = _HOST if _HOST_TRIED else _host_module()
@@ -1684,7 +1684,7 @@ def vtrace_advantage_estimate(
     Returns ``(advantages, vs)``.  ``terminated=None`` makes ``not_terminated = not_done``.
     """
     if torch.compiler.is_compiling():
-        (g, gt), (rs, rt), (cs, ct) = _ops._split(gamma), _ops._split(rho_thresh), _ops._split(c_thresh)
+        (g, gt), (rs, rt), (cs, ct) = _ops._split_leaf(gamma, next_state_value.shape, time_dim), _ops._split(rho_thresh), _ops._split(c_thresh)
         return _ops.vtrace_op(log_pi, log_mu, state_value, next_state_value, reward, done, done if terminated is None else terminated,
                               g, gt, rs, cs, rt, ct, time_dim)
     host = _HOST if _HOST_TRIED else _host_module()
