@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include "scan_core.h"
+#include "moment_gather.h"
 
 namespace {
 
@@ -365,12 +366,12 @@ __global__ __launch_bounds__(kLongThreads) void scan_long_kernel(typename Op::Ar
 // the flag with agent-scope loads and reads the payload with agent-scope loads
 // (MI355X_MICROARCH.md, valid hand-off forms).  Ticket and records are zeroed by a memset node on the
 // same stream before every launch.  Spins are bounded (1 s): on timeout NaNs are written.
-struct LbRecord {             // one 64-byte line per chunk; a field is never rewritten once its flag is up
-    unsigned long long flag;  // 0 none, 1 aggregate {a, b} valid, 2 inclusive {x} valid too
-    unsigned long long a, b;  // aggregate map of the chunk (double bits)
-    unsigned long long x;     // inclusive value: x of the chunk's first step
-    unsigned long long v0;    // V-trace: state_value of the chunk's first step
-    unsigned long long pad[3];
+struct LbRecord {             // one 64-byte line per chunk, zeroed before every launch; every 8-byte word carries its own state in
+                              // its low 2 bits (0 = not written yet) and is never rewritten once set
+    unsigned long long a, b;  // aggregate map of the chunk: double bits | 1, one 16-byte store
+    unsigned long long x;     // inclusive value (x of the chunk's first step): double bits | 2
+    unsigned long long v0;    // V-trace: state_value of the chunk's first step: double bits | 1
+    unsigned long long pad[4];
 };
 static_assert(sizeof(LbRecord) == 64, "record size");
 constexpr int kLbMaxRows = 512;
@@ -384,11 +385,25 @@ template <typename T>
 __device__ __forceinline__ unsigned long long lb_bits(T x) { return (unsigned long long)__double_as_longlong((double)x); }
 template <typename T>
 __device__ __forceinline__ T lb_val(unsigned long long b) { return (T)__longlong_as_double((long long)b); }
+// The state rides in the two low mantissa bits of the double: nothing is lost for fp32 carries (29 zero bits there), 2^-51
+// relative for fp64 ones.  One poll = ONE round trip: both 16-byte halves {a, b} and {x, v0} of a record are loaded together.
+__device__ __forceinline__ unsigned long long lb_tag(unsigned long long bits, unsigned state) { return (bits & ~3ull) | state; }
+template <typename T>
+__device__ __forceinline__ T lb_untag(unsigned long long b) { return lb_val<T>(b & ~3ull); }
 __device__ __forceinline__ void lb_store(unsigned long long *p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ unsigned long long lb_load(const unsigned long long *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void lb_store2(unsigned long long *p, unsigned long long v0, unsigned long long v1) {
+    gather::store_granule(p, v0, v1);
+}
+__device__ __forceinline__ void lb_load_record(const LbRecord *r, gather::u64x2 &ab, gather::u64x2 &xv) {
+    asm volatile(
+        "global_load_dwordx4 %0, %2, off sc1\n\t"
+        "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(ab), "=&v"(xv)
+        : "v"(r)
+        : "memory");
 }
 
 constexpr int kLbTeams = 4;  // teams per look-back block: one ticket / one record per 4 * 256 * V steps
@@ -467,19 +482,11 @@ __global__ __launch_bounds__(kLbTeams * kTeam, LbWavesPerSimd<Op>::value) void s
                 bool ok = true;
                 if (agg.h) {
                     // the block holds its row's end: inclusive value known at once
-                    if (lane == 0) {
-                        lb_store(&myrec->x, lb_bits(agg.b));
-                        lb_store(&myrec->v0, lb_bits(my_v0));
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        lb_store(&myrec->flag, 2ull);
-                    }
+                    if (lane == 0) lb_store2(&myrec->x, lb_tag(lb_bits(agg.b), 2u), lb_tag(lb_bits(my_v0), 1u));
                 } else {
                     if (lane == 0) {
-                        lb_store(&myrec->a, lb_bits(agg.a));
-                        lb_store(&myrec->b, lb_bits(agg.b));
-                        lb_store(&myrec->v0, lb_bits(my_v0));
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        lb_store(&myrec->flag, 1ull);
+                        lb_store2(&myrec->a, lb_tag(lb_bits(agg.a), 1u), lb_tag(lb_bits(agg.b), 1u));
+                        if (Op::kNeedsNext) lb_store(&myrec->v0, lb_tag(lb_bits(my_v0), 1u));
                     }
                     // look back: lane l reads the record of chunk base + l; the records up to the first inclusive
                     // one are composed in chunk order by a wave reduction; no inclusive among the 64 -> next 64
@@ -489,22 +496,28 @@ __global__ __launch_bounds__(kLbTeams * kTeam, LbWavesPerSimd<Op>::value) void s
                         const int idx = base + lane;
                         const bool valid = idx < nchunks;
                         const LbRecord *r = rec + row * nchunks + (valid ? idx : nchunks - 1);
-                        unsigned long long f = 0ull;
+                        const bool want_v0 = Op::kNeedsNext && base == c + 1 && lane == 0;
+                        gather::u64x2 ab = {0ull, 0ull}, xv = {0ull, 0ull};
+                        bool have_agg = false, have_incl = false, ready = false;
                         int first = kWave;
                         for (;;) {
-                            if (valid && f == 0ull) f = lb_load(&r->flag);  // only the records still missing are re-polled
-                            const unsigned long long incl = __ballot(valid && f == 2ull);
+                            if (valid && !ready) {  // only the records still missing are re-polled
+                                lb_load_record(r, ab, xv);
+                                have_agg = (ab.x & 3ull) == 1ull && (ab.y & 3ull) == 1ull;
+                                have_incl = (xv.x & 3ull) == 2ull;
+                                ready = (have_agg || have_incl) && (!want_v0 || (xv.y & 3ull) == 1ull);
+                            }
+                            const unsigned long long incl = __ballot(valid && ready && have_incl);
                             first = incl ? (int)__ffsll((long long)incl) - 1 : kWave;
-                            if (__all(!(valid && lane <= first) || f != 0ull)) break;
+                            if (__all(!(valid && lane <= first) || ready)) break;
                             if (wall_clock64() - t_start > 100000000ull) { ok = false; break; }
-                            __builtin_amdgcn_s_sleep(1);
                         }
                         if (!ok) break;
                         if (first == kWave && !__all(valid)) { ok = false; break; }  // ran past the row's end: cannot happen
                         Aff<TC> el{(TC)1, (TC)0, 0};
-                        if (valid && lane < first) el = Aff<TC>{lb_val<TC>(lb_load(&r->a)), lb_val<TC>(lb_load(&r->b)), 0};
-                        else if (valid && lane == first) el = Aff<TC>{(TC)0, lb_val<TC>(lb_load(&r->x)), 1};  // constant map
-                        if (base == c + 1 && lane == 0) carry_v = lb_val<TS>(lb_load(&r->v0));
+                        if (valid && lane < first) el = Aff<TC>{lb_untag<TC>(ab.x), lb_untag<TC>(ab.y), 0};
+                        else if (valid && lane == first) el = Aff<TC>{(TC)0, lb_untag<TC>(xv.x), 1};  // constant map
+                        if (want_v0) carry_v = lb_untag<TS>(xv.y);
 #pragma unroll
                         for (int off = 1; off < kWave; off <<= 1) {
                             const Aff<TC> p = shfl_down_aff(el, off);
@@ -518,11 +531,7 @@ __global__ __launch_bounds__(kLbTeams * kTeam, LbWavesPerSimd<Op>::value) void s
                         carry = (TC)__longlong_as_double(0x7ff8000000000000LL);
                         if (lane == 0) hdr->error = 1u;
                     }
-                    if (lane == 0) {
-                        lb_store(&myrec->x, lb_bits(apply(agg, carry)));
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        lb_store(&myrec->flag, 2ull);
-                    }
+                    if (lane == 0) lb_store(&myrec->x, lb_tag(lb_bits(apply(agg, carry)), 2u));
                 }
                 if (lane == 0) {
                     // carries into the teams, last team first: what follows team tm is team tm+1 ... then `carry`
