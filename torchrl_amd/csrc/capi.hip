@@ -153,6 +153,19 @@ static bool prefer_lockstep(int val_dtype, int coef_dtype, int64_t T, int64_t I)
     return R * T * I * 100 < chunk * 95;
 }
 
+// GAE only (round 3): rows of 64 < T <= 128 steps go through the transposing kernel as 16-lane DPP rows (gae_interleaved.h,
+// VR > 0), which beats the lock-step kernels at every chunk fill measured as long as the chunk keeps its 16-byte accesses
+// (transposing / lock-step us: [4096x80x5] 7.9 / 12.8, [4096x96x4] 7.7 / 9.9, [4096x70x3] 6.3 / 7.9, [8192x100x3] 11.6 / 15.0,
+// [4096x65x7] 14.0 / 17.4, [4096x100x8] 15.2 / 18.5; fp64 [4096x100x2] 7.6 / 9.5, [4096x80x3] 7.2 / 12.8, [8192x128x3]
+// 22.6 / 29.2; without them, [4096x127x3]: 13.2 / 9.9).
+static bool gae_rows_as_dpp_rows(int val_dtype, int coef_dtype, int64_t T, int64_t I) {
+    if (val_dtype != coef_dtype || I < 2 || T <= 64 || T > 128) return false;
+    const int64_t V = val_dtype == TRL_F32 ? 4 : 2, chunk = 256 * V;
+    if (T * I > chunk) return false;
+    const int64_t R = chunk / (T * I);
+    return (R * T * I) % V == 0;
+}
+
 // Outer rows too long for the transposing kernel, 9 <= I <= 31: lock-step groups or the SEQ walk (coalesced only
 // over i, but every (o, i) row is a lane).  Measured fp32 (SEQ / LOCKSTEP us): [64x1000x16] 381 / 20, [1024x300x16]
 // 145 / 62, [4096x300x16] 281 / 218, [1024x100x31] 68 / 65, [8192x100x16] 117 / 146, [16384x64x31] 360 / 817:
@@ -204,7 +217,8 @@ static int gae_fwd_impl(void *stream, int val_dtype, int coef_dtype, const void 
     LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
     size_t lb_bytes = 0;
     void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
-    if (algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I)) res = launch_gae_lockstep(s, val_dtype, coef_dtype, a);
+    if (algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I) && !gae_rows_as_dpp_rows(val_dtype, coef_dtype, T, I))
+        res = launch_gae_lockstep(s, val_dtype, coef_dtype, a);
     if (res.status == TRL_ERR_UNSUPPORTED && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN))
         res = launch_gae_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)
