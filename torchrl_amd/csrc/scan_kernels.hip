@@ -23,6 +23,10 @@ LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a, 
                     aligned16(a.value_target);
     auto go = [&](auto op) {
         typedef decltype(op) Op;
+        // I == 1, rows of 64 < T <= 128 steps that do not tile a wave, sent through the interleaved kernel as well (an LDS turn
+        // buys the row phase its own lane mapping) were measured: short-row kernel / that, us: [20480x100] 9.35 / 8.78,
+        // [65536x100] 32.8 / 29.7, [20480x80] 8.0 / 7.5, fp64 [20480x80] 17.9 / 14.7 -- 5 - 10 %, not taken: the un-normalised
+        // scan would stop being the very scan of the fused kernel (bit-equal value_target on both routes).
         Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus(), lb_ws ? lb_bytes : 0, a.partials != nullptr);
         if (!p.ok) return LaunchResult{2, 0, nullptr};
         if constexpr (!Op::kShifted) {
