@@ -163,7 +163,9 @@ MULTI = [((40, 50, 5, 1), -3), ((6, 9, 2, 5), 1), ((33, 17, 64), -2), ((4, 300, 
          # 64 < T <= 128: the GAE kernel's row phase gives every (o, i) row a 16-lane DPP row, 5 - 8 steps per lane
          # (gae_interleaved.h, VR > 0); last chunk short of rows, rows short of 16 * VR steps, T * I just under a chunk
          ((33, 80, 5, 1), -3), ((21, 96, 4), -2), ((37, 65, 7), -2), ((9, 113, 9), -2), ((5, 66, 15), -2), ((11, 120, 8), -2),
-         ((70, 100, 2), -2), ((3, 128, 8), -2), ((1, 97, 1, 3), 1)]
+         ((70, 100, 2), -2), ((3, 128, 8), -2), ((1, 97, 1, 3), 1),
+         # 128 < T <= 256: two DPP rows (32 lanes) per (o, i) row
+         ((13, 200, 5), -2), ((7, 160, 3), -2), ((9, 250, 4), -2), ((5, 136, 7), -2), ((3, 255, 4), -2), ((6, 129, 2), -2), ((40, 200, 2, 1), -3)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
@@ -400,7 +402,7 @@ def test_workspace_error_word_is_clear_after_fused_calls():
 
 
 BCAST = [((40, 50, 5, 1), -3), ((6, 9, 2, 5), 1), ((33, 17, 64), -2), ((4096, 100, 5, 1), -3), ((7, 3, 2), -2), ((50, 16, 4), -2),
-         ((19, 101, 3), -2), ((64, 25, 4), 1), ((4, 300, 130), -2), ((33, 80, 5, 1), -3), ((21, 96, 4), -2), ((9, 113, 9), -2)]
+         ((19, 101, 3), -2), ((64, 25, 4), 1), ((4, 300, 130), -2), ((33, 80, 5, 1), -3), ((21, 96, 4), -2), ((9, 113, 9), -2), ((13, 200, 5), -2), ((7, 160, 3, 1), -3)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])

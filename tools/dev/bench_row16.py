@@ -8,10 +8,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from torchrl_amd.objectives.value import functional as F  # noqa: E402
 from tools.bench_configs import inputs, timeit  # noqa: E402
 
-for dt, shape in [(torch.float32, s_) for s_ in ((4096, 100, 5, 1), (4096, 80, 5, 1), (4096, 96, 4, 1), (4096, 70, 3, 1), (4096, 112, 3, 1), (4096, 120, 2, 1), (4096, 127, 3, 1), (8192, 100, 2, 1), (8192, 100, 3, 1), (8192, 85, 6, 1), (8192, 128, 2, 1), (4096, 65, 7, 1), (4096, 100, 8, 1))] + [(torch.float64, s_) for s_ in ((4096, 100, 5, 1), (4096, 100, 2, 1), (4096, 80, 3, 1), (8192, 128, 3, 1))]:
+SHAPES32 = [(torch.float32, s_) for s_ in ((8192, 64, 4, 1), (8192, 128, 4, 1), (8192, 32, 8, 1), (8192, 50, 5, 1), (8192, 40, 3, 1), (8192, 20, 7, 1),
+                                            (4096, 100, 3, 1), (8192, 60, 6, 1), (4096, 127, 3, 1), (4096, 33, 5, 1), (4096, 99, 3, 1), (8192, 16, 16, 1),
+                                            (8192, 10, 2, 1), (65536, 8, 3, 1), (4096, 200, 4, 1), (8192, 48, 4, 1))] \
+    + [(torch.float64, s_) for s_ in ((8192, 64, 4, 1), (8192, 50, 5, 1), (8192, 32, 8, 1), (8192, 40, 3, 1), (4096, 99, 3, 1), (8192, 24, 4, 1))]
+for dt, shape in SHAPES32:
     r, v, nv, d, t, *_ = inputs(shape, dt, 0.01, mask_shape=shape[:2] + (1, 1))
     call = F._prepare_gae(0.9, 0.9, v, nv, r, d, t, -3)
     for algo in (F.ALGO_AUTO, F.ALGO_SCAN, F.ALGO_LOCKSTEP):
         st = F.prepare_gae_step(call, normalize=False, algo=algo)
         us = min(timeit(st.run, 400) for _ in range(5))
-        print(f"{str(dt)[6:]} {str(shape):22s} algo {algo} {us:7.2f} us  [{F.last_kernel()}] row16={'off' if os.environ.get('TRL_GIL_ROW16_OFF') else 'on'}", flush=True)
+        print(f"{str(dt)[6:]} {str(shape):22s} algo {algo} {us:7.2f} us  [{F.last_kernel()}] row32={'off' if os.environ.get('TRL_GIL_ROW32_OFF') else 'on'}", flush=True)

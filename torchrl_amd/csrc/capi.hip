@@ -153,17 +153,22 @@ static bool prefer_lockstep(int val_dtype, int coef_dtype, int64_t T, int64_t I)
     return R * T * I * 100 < chunk * 95;
 }
 
-// GAE only (round 3): rows of 64 < T <= 128 steps go through the transposing kernel as 16-lane DPP rows (gae_interleaved.h,
-// VR > 0), which beats the lock-step kernels at every chunk fill measured as long as the chunk keeps its 16-byte accesses
-// (transposing / lock-step us: [4096x80x5] 7.9 / 12.8, [4096x96x4] 7.7 / 9.9, [4096x70x3] 6.3 / 7.9, [8192x100x3] 11.6 / 15.0,
-// [4096x65x7] 14.0 / 17.4, [4096x100x8] 15.2 / 18.5; fp64 [4096x100x2] 7.6 / 9.5, [4096x80x3] 7.2 / 12.8, [8192x128x3]
-// 22.6 / 29.2; without them, [4096x127x3]: 13.2 / 9.9).
-static bool gae_rows_as_dpp_rows(int val_dtype, int coef_dtype, int64_t T, int64_t I) {
-    if (val_dtype != coef_dtype || I < 2 || T <= 64 || T > 128) return false;
+// GAE only (round 3): GAE has its own transposing kernel (gae_interleaved.h: 2 arrays instead of 5 cross LDS; rows of 64 < T <= 256
+// steps as 16- / 32-lane groups in the row phase) and the rule above, measured on the generic kernel, no longer describes it.
+// Transposing / lock-step us at every chunk fill (profiles/r03_gae_rows_as_dpp_rows.txt): [4096x80x5] 7.9 / 12.8, [4096x96x4]
+// 7.6 / 9.9, [8192x64x4] 8.1 / 10.1, [8192x40x3] 6.7 / 8.0, [8192x60x6] 15.4 / 22.3, [4096x136x7] 16.9 / 31.7, [4096x160x3]
+// 8.2 / 14.4, [4096x200x4] 15.8 / 17.8, [8192x48x4] 9.0 / 9.1; fp64 [8192x40x3] 8.3 / 12.7, [8192x24x4] 8.1 / 10.2, [4096x160x3]
+// 15.4 / 25.9, [4096x99x3] 12.4 / 16.9.  The exception: fp32 chunks that lose their 16-byte accesses (R*T*I not a multiple of
+// 4: [4096x127x3] 13.0 / 9.8, [4096x99x3] 11.8 / 9.4) stay with the rule above.
+static bool gae_prefers_transposing(int val_dtype, int coef_dtype, int64_t T, int64_t I) {
+    if (val_dtype != coef_dtype || I < 2) return false;
     const int64_t V = val_dtype == TRL_F32 ? 4 : 2, chunk = 256 * V;
     if (T * I > chunk) return false;
-    const int64_t R = chunk / (T * I);
-    return (R * T * I) % V == 0;
+    int64_t R = chunk / (T * I), g = T * I, v = V;  // make_plan's rows per chunk (scan_impl.h)
+    while (v) { const int64_t t = g % v; g = v; v = t; }
+    const int64_t q = V / g;
+    if (R >= q) R -= R % q;
+    return val_dtype == TRL_F64 || (R * T * I) % V == 0;
 }
 
 // Outer rows too long for the transposing kernel, 9 <= I <= 31: lock-step groups or the SEQ walk (coalesced only
@@ -217,7 +222,7 @@ static int gae_fwd_impl(void *stream, int val_dtype, int coef_dtype, const void 
     LaunchResult res{TRL_ERR_UNSUPPORTED, 0, nullptr};
     size_t lb_bytes = 0;
     void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
-    if (algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I) && !gae_rows_as_dpp_rows(val_dtype, coef_dtype, T, I))
+    if (algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I) && !gae_prefers_transposing(val_dtype, coef_dtype, T, I))
         res = launch_gae_lockstep(s, val_dtype, coef_dtype, a);
     if (res.status == TRL_ERR_UNSUPPORTED && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN))
         res = launch_gae_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);

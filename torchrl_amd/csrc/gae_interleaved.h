@@ -41,12 +41,13 @@ struct GaePreparedOp {  // what scan_chunk needs of an estimator whose per-step 
 // against 9.5 -- the idle lanes and the fewer resident chunks cost more than the stage it removes.  Dropped.
 constexpr int kGilBlocksPerCu = 4;  // resident blocks per CU = the grid's blocks per CU (measured above)
 
-// VR > 0: the row phase gives every (o, i) row one 16-lane DPP row and every lane VR consecutive steps (T <= 16 * VR, at most
-// 16 rows per chunk): a row never leaves its DPP row, so the scan is four row shifts -- no hard-reset flags, no cross-row
+// VR > 0: the row phase gives every (o, i) row LG = 16 lanes (one DPP row; LG = 32: two, chained by one shuffle) and every lane
+// VR consecutive steps (T <= LG * VR, at most 256 / LG rows per chunk): a row never leaves its DPP row, so the scan is four row shifts -- no hard-reset flags, no cross-row
 // steps, no cross-wave stage and no barrier of its own -- at the price of idle lanes in that phase (C3: 10 rows = 160 of 256
 // lanes, 100 of 112 steps).  The memory-order phases (V elements per lane, 16-byte accesses) are the same.  Measured: C3 9.55 ->
-// 8.49 us back-to-back, 10.45 -> 9.28 us rocprofv3 average; [4096x112x3] 9.16 -> 8.08; fp64 C3 17.65 -> 16.6.
-template <typename TS, typename TG, int V, int VR, bool VEC, bool WAVE_INDEP, bool PAD>
+// 8.49 us back-to-back, 10.45 -> 9.28 us rocprofv3 average; [4096x112x3] 9.16 -> 8.08; fp64 C3 17.65 -> 16.6; LG = 32 (128 < T <=
+// 256): [4096x200x5] 19.4 -> 17.8, [4096x160x3] 9.55 -> 8.2, [4096x136x7] 18.7 -> 16.9, fp64 [4096x160x3] 16.5 -> 15.4.
+template <typename TS, typename TG, int V, int VR, int LG, bool VEC, bool WAVE_INDEP, bool PAD>
 __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel(GaeArgs args, ScanGeom geo, int I, double *partials) {
     typedef typename Promote<TS, TG>::type TC;
     typedef GaePreparedOp<TS, TC, V> Op;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel
     constexpr int NR = VR > 0 ? VR : 1;
     int pr[NR];  // VR > 0: LDS offsets of the lane's steps in the row phase (-1: past the row's end)
     if constexpr (VR > 0) {
-        const unsigned g = threadIdx.x >> 4, j = threadIdx.x & 15u;
+        const unsigned g = threadIdx.x / LG, j = threadIdx.x % LG;
         const unsigned ol = g / (unsigned)I, i = g % (unsigned)I;
 #pragma unroll
         for (int e = 0; e < VR; ++e) {
@@ -172,8 +173,8 @@ __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel
         __syncthreads();
         // ---- row order: gather, scan, scatter the advantage ------------------------------------------------------------
         if constexpr (VR > 0) {
-            const bool row_ok = (int)(threadIdx.x >> 4) * (int)T < count;  // this 16-lane row holds one of the chunk's nrows * I rows
-            const int j = threadIdx.x & 15;
+            const bool row_ok = (int)(threadIdx.x / LG) * (int)T < count;  // this lane group holds one of the chunk's nrows * I rows
+            const int j = threadIdx.x % LG, jr = threadIdx.x & 15;
             TC dl[VR], dc[VR];
 #pragma unroll
             for (int e = 0; e < VR; ++e) {
@@ -187,15 +188,20 @@ __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel
 #define TRL_ROW_STEP(OFF)                                                                  \
     {                                                                                      \
         const Aff<TC> p{dpp_mov<0x100 + OFF>(S.a), dpp_mov<0x100 + OFF>(S.b), 0};          \
-        if (j + OFF < 16) S = compose_t<false>(S, p);                                      \
+        if (jr + OFF < 16) S = compose_t<false>(S, p);                                     \
     }
             TRL_ROW_STEP(1)
             TRL_ROW_STEP(2)
             TRL_ROW_STEP(4)
             TRL_ROW_STEP(8)
 #undef TRL_ROW_STEP
-            TC x = dpp_mov<0x101>(S.b);  // everything after this lane applied to 0; lane 15 of the row: nothing follows
-            if (j == 15) x = (TC)0;
+            if constexpr (LG == 32) {  // two DPP rows per (o, i) row: the first absorbs the second's total (its lane 0)
+                const int src = (threadIdx.x & 32) | 16;
+                const Aff<TC> p{__shfl(S.a, src, kWave), __shfl(S.b, src, kWave), 0};
+                if (j < 16) S = compose_t<false>(S, p);
+            }
+            TC x = dpp_mov<0x130>(S.b);  // everything after this lane applied to 0 (whole-wave shift by one lane) ...
+            if (j == LG - 1) x = (TC)0;  // ... the row's last lane: nothing follows
 #pragma unroll
             for (int e = VR - 1; e >= 0; --e) {
                 x = dl[e] + x * dc[e];
@@ -259,30 +265,35 @@ LaunchResult launch_gae_interleaved(hipStream_t s, const GaeArgs &a, const Plan 
     if (nb > (i64)cus * kGilBlocksPerCu) nb = (i64)cus * kGilBlocksPerCu;
     if (nb > 4096) nb = 4096;  // per-block partials: scan_max_partials
     typedef typename Promote<TS, TG>::type TC;
-    // rows as 16-lane DPP rows (VR steps per lane) when the chunk's rows fit 16 of them and T does not tile a wave anyway
+    // rows as 16- / 32-lane groups (VR steps per lane) when T does not tile a wave anyway: 64 < T <= 128 / 128 < T <= 256
     const i64 rows = (i64)p.rows_per_chunk * a.I;
-    const int vr = (int)((a.T + 15) / 16);
-    const bool row16 = rows <= 16 && vr >= 5 && vr <= 8 && !p.wave_indep;
-    const i64 stride_words = (i64)(row16 ? vr : V) * a.I * (i64)(sizeof(TC) / 4);
+    int lg = 0;
+    if (!p.wave_indep && a.T > 64 && a.T <= 128) lg = 16;
+    if (!p.wave_indep && a.T > 128 && a.T <= 256) lg = 32;
+    const int vr = lg ? (int)((a.T + lg - 1) / lg) : 0;
+    const bool rowmap = lg != 0 && rows <= kTeam / lg && vr >= 5 && vr <= 8;
+    const i64 stride_words = (i64)(rowmap ? vr : V) * a.I * (i64)(sizeof(TC) / 4);
     const bool pad_lds = stride_words % 8 == 0;
     const dim3 grid((unsigned)nb);
-#define TRL_GIL(VR, VEC, WI)                                                                                                    \
+#define TRL_GIL(VR, LG, VEC, WI)                                                                                                \
     do {                                                                                                                        \
-        if (pad_lds) hipLaunchKernelGGL((gae_interleaved_kernel<TS, TG, V, VR, VEC, WI, true>), grid, dim3(kTeam), 0, s, a, geo, (int)a.I, a.partials); \
-        else hipLaunchKernelGGL((gae_interleaved_kernel<TS, TG, V, VR, VEC, WI, false>), grid, dim3(kTeam), 0, s, a, geo, (int)a.I, a.partials);         \
+        if (pad_lds) hipLaunchKernelGGL((gae_interleaved_kernel<TS, TG, V, VR, LG, VEC, WI, true>), grid, dim3(kTeam), 0, s, a, geo, (int)a.I, a.partials); \
+        else hipLaunchKernelGGL((gae_interleaved_kernel<TS, TG, V, VR, LG, VEC, WI, false>), grid, dim3(kTeam), 0, s, a, geo, (int)a.I, a.partials);         \
     } while (0)
-#define TRL_GIL_ROW(VR) { if (p.vec) TRL_GIL(VR, true, false); else TRL_GIL(VR, false, false); }
-    if (row16) {
-        switch (vr) {
-            case 5: TRL_GIL_ROW(5) break;
-            case 6: TRL_GIL_ROW(6) break;
-            case 7: TRL_GIL_ROW(7) break;
-            default: TRL_GIL_ROW(8) break;
-        }
+#define TRL_GIL_ROW(VR, LG) { if (p.vec) TRL_GIL(VR, LG, true, false); else TRL_GIL(VR, LG, false, false); }
+#define TRL_GIL_ROWS(LG)                          \
+    switch (vr) {                                 \
+        case 5: TRL_GIL_ROW(5, LG) break;         \
+        case 6: TRL_GIL_ROW(6, LG) break;         \
+        case 7: TRL_GIL_ROW(7, LG) break;         \
+        default: TRL_GIL_ROW(8, LG) break;        \
     }
+    if (rowmap && lg == 16) { TRL_GIL_ROWS(16) }
+    else if (rowmap) { TRL_GIL_ROWS(32) }
+    else if (p.wave_indep) { if (p.vec) TRL_GIL(0, 16, true, true); else TRL_GIL(0, 16, false, true); }
+    else              { if (p.vec) TRL_GIL(0, 16, true, false); else TRL_GIL(0, 16, false, false); }
+#undef TRL_GIL_ROWS
 #undef TRL_GIL_ROW
-    else if (p.wave_indep) { if (p.vec) TRL_GIL(0, true, true); else TRL_GIL(0, false, true); }
-    else              { if (p.vec) TRL_GIL(0, true, false); else TRL_GIL(0, false, false); }
 #undef TRL_GIL
     return LaunchResult{0, nb, "gae_scan_interleaved"};
 }
