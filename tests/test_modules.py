@@ -301,3 +301,88 @@ def test_module_one_hop_route_equals_general_route(dtype, default_dtype, monkeyp
                 assert torch.equal(a, b), f"{k}: {(a - b).abs().max().item()}"
     finally:
         torch.set_default_dtype(old)
+
+
+@pytest.mark.gpu
+def test_gae_short_forward_covers_only_the_plain_case(monkeypatch):
+    """``GAE.forward`` resolves the plain case (RolloutData, string keys, scalar buffers, nothing to differentiate) with a
+    handful of dict look-ups and one hop to the C ABI; everything else goes the long way and gives the same numbers."""
+    m = GAE(gamma=0.98, lmbda=0.94, value_network=None, average_gae=True, device=DEV)
+    took = []
+    orig = GAE._short_forward
+
+    def spy(self, data):
+        out = orig(self, data)
+        took.append(out is not None)
+        return out
+
+    monkeypatch.setattr(GAE, "_short_forward", spy)
+    d = _data(seed=5)
+    assert m(d) is d and took == [True]
+    ref = (d.get("advantage").clone(), d.get("value_target").clone())
+
+    def same(data, adv_key="advantage"):
+        assert torch.equal(data.get(adv_key), ref[0]) and torch.equal(data.get("value_target"), ref[1])
+
+    d2 = _data(seed=5)
+    m(d2, time_dim=-1)                       # explicit time_dim: not even tried
+    assert took == [True]
+    same(d2)
+    d3 = _data(seed=5)
+    d3.names = [None, "time"]                # named dims
+    m(d3)
+    assert took[-1] is False
+    same(d3)
+    m.set_keys(advantage=("out", "adv"))     # nested key
+    d4 = _data(seed=5)
+    m(d4)
+    assert took[-1] is False
+    same(d4, ("out", "adv"))
+    m.set_keys(advantage="adv2")             # renamed string key: still the short way
+    d4b = _data(seed=5)
+    m(d4b)
+    assert took[-1] is True
+    same(d4b, "adv2")
+    m.set_keys(advantage="advantage")
+    d5 = _data(seed=5)
+    d5.set("steps_to_next_obs", torch.ones(4, 10, 1, dtype=torch.long, device=DEV))
+    m(d5)
+    assert took[-1] is False
+    torch.testing.assert_close(d5.get("advantage"), ref[0], rtol=1e-5, atol=1e-5)   # gamma ** 1 as a tensor: the per-element path
+    d6 = _data(seed=5)
+    d6.get("state_value").requires_grad_()
+    m(d6)                                    # grad mode on, input requires grad: the long way (computed under no_grad)
+    assert took[-1] is False and not d6.get("advantage").requires_grad
+    same(d6)
+    with torch.no_grad():
+        d6b = _data(seed=5)
+        d6b.get("state_value").requires_grad_()
+        m(d6b)
+        assert took[-1] is True
+        same(d6b)
+    d7 = _data(seed=5)
+    del d7.to_dict()["next"]["terminated"]   # terminated defaults to done on both ways
+    m(d7)
+    assert took[-1] is True
+    d7b = _data(seed=5)
+    del d7b.to_dict()["next"]["terminated"]
+    m(d7b, time_dim=-1)
+    assert torch.equal(d7.get("advantage"), d7b.get("advantage"))
+    with pytest.raises(KeyError):            # a missing entry raises what the long way raises
+        m(RolloutData({"state_value": torch.zeros(4, 10, 1, device=DEV)}, batch_size=[4, 10]))
+    m.gamma = torch.tensor(0.5, device=DEV)  # replaced buffer: the cached coefficients go
+    d8 = _data(seed=5)
+    m(d8)
+    assert took[-1] is True and not torch.equal(d8.get("advantage"), ref[0])
+    d8b = _data(seed=5)
+    m(d8b, time_dim=-1)
+    assert torch.equal(d8.get("advantage"), d8b.get("advantage"))
+    m.gamma.fill_(0.98)                      # modified in place
+    d9 = _data(seed=5)
+    m(d9)
+    same(d9)
+    cpu = GAE(gamma=0.98, lmbda=0.94, value_network=None, average_gae=True)
+    dc = _data(seed=5, device="cpu")
+    cpu(dc)                                  # host tensors: declined, the CPU path answers
+    assert took[-1] is False
+    torch.testing.assert_close(dc.get("advantage"), ref[0].cpu(), rtol=1e-5, atol=1e-5)
