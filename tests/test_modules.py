@@ -386,3 +386,52 @@ def test_gae_short_forward_covers_only_the_plain_case(monkeypatch):
     cpu(dc)                                  # host tensors: declined, the CPU path answers
     assert took[-1] is False
     torch.testing.assert_close(dc.get("advantage"), ref[0].cpu(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls", [TDLambdaEstimator, TD1Estimator])
+@pytest.mark.parametrize("vectorized", [True, False])
+def test_td_short_forward_equals_the_long_way(cls, vectorized, monkeypatch):
+    if cls is TD1Estimator and not vectorized:
+        pytest.skip("TD1Estimator has no loop variant")
+    kw = dict(_kw(cls))
+    if cls is TDLambdaEstimator:
+        kw["vectorized"] = vectorized
+    took = []
+    orig = TDLambdaEstimator._short_forward
+
+    def spy(self, data):
+        out = orig(self, data)
+        took.append(out is not None)
+        return out
+
+    monkeypatch.setattr(TDLambdaEstimator, "_short_forward", spy)
+    m = cls(**kw, device=DEV)
+    d = _data(seed=8)
+    assert m(d) is d and took == [True]
+    m.time_dim = -1                      # the attribute sends forward the long way
+    d2 = _data(seed=8)
+    m(d2)
+    assert took == [True]
+    for k in ("advantage", "value_target"):
+        assert torch.equal(d.get(k), d2.get(k)), k
+    m.time_dim = None
+    d3 = _data(seed=8)
+    d3.set(("next", "state_value"), d3.get(("next", "state_value")).double())   # fp64 values, fp32 buffers: still floats
+    d3.set("state_value", d3.get("state_value").double())
+    d3.set(("next", "reward"), d3.get(("next", "reward")).double())
+    m(d3)
+    assert took[-1] is True and d3.get("value_target").dtype == torch.float64
+    m64 = cls(**{**kw, "gamma": torch.tensor(0.98, dtype=torch.float64)}, device=DEV)
+    d4, d5 = _data(seed=8), _data(seed=8)
+    m64(d4)                              # a wider buffer widens the vec variant's result: the long way decides
+    assert took[-1] is (not vectorized)
+    m64.time_dim = -1
+    m64(d5)
+    assert d4.get("value_target").dtype == d5.get("value_target").dtype and torch.equal(d4.get("value_target"), d5.get("value_target"))
+    m.gamma.fill_(0.5)
+    d6, d7 = _data(seed=8), _data(seed=8)
+    m(d6)
+    m.time_dim = -1
+    m(d7)
+    assert torch.equal(d6.get("advantage"), d7.get("advantage")) and not torch.equal(d6.get("advantage"), d.get("advantage"))

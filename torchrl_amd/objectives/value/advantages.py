@@ -630,7 +630,53 @@ class TDLambdaEstimator(ValueEstimatorBase):
         self.time_dim = time_dim
         self._lmbda_one = False
 
+    def _short_forward(self, data):
+        """``forward`` for the plain case (see ``GAE._short_forward``): dict look-ups, the buffers as python floats where those
+        act exactly like the buffers, the return estimate through the one-hop host path.  None: not that case."""
+        tk = self._tensor_keys
+        if tk is None:
+            tk = self.tensor_keys
+        vk, rk, dk, tmk, ak, vtk, sk = tk.value, tk.reward, tk.done, tk.terminated, tk.advantage, tk.value_target, tk.steps_to_next_obs
+        d = data._d
+        nxt = d.get("next")
+        if (nxt.__class__ is not dict or vk.__class__ is not str or rk.__class__ is not str or dk.__class__ is not str
+                or tmk.__class__ is not str or ak.__class__ is not str or vtk.__class__ is not str or sk.__class__ is not str or sk in d):
+            return None
+        names = data.names
+        if len(data.batch_size) < 1 or names.count(None) != len(names):
+            return None
+        try:
+            value, next_value, reward, done = d[vk], nxt[vk], nxt[rk], nxt[dk]
+            terminated = nxt.get(tmk, done)
+            if torch.is_grad_enabled() and (value.requires_grad or next_value.requires_grad or reward.requires_grad):
+                return None
+            dt = next_value.dtype
+        except (KeyError, TypeError, AttributeError):
+            return None
+        buffers = self._buffers
+        gamma = buffers["gamma"]
+        if gamma.numel() != 1 or (self.vectorized and torch.promote_types(dt, gamma.dtype) != dt):
+            return None
+        lmbda = 1.0
+        if not self._lmbda_one:
+            lmbda = buffers["lmbda"]
+            if lmbda.numel() != 1 or (self.vectorized and torch.promote_types(dt, lmbda.dtype) != dt):
+                return None
+            lmbda = self._host_float(lmbda)
+        fn = F.vec_td_lambda_return_estimate if self.vectorized else F.td_lambda_return_estimate
+        value_target = fn(self._host_float(gamma), lmbda, next_value, reward, done=done, terminated=terminated,
+                          time_dim=len(data.batch_size) - 1)
+        d[ak] = value_target - value
+        d[vtk] = value_target
+        return data
+
     def forward(self, *args, params=None, target_params=None, **kwargs):
+        if (len(args) == 1 and args[0].__class__ is RolloutData and not kwargs and params is None and target_params is None
+                and self.time_dim is None and self.value_network is None and not self.differentiable and not self.skip_existing
+                and not self.average_rewards):
+            done_data = self._short_forward(args[0])
+            if done_data is not None:
+                return done_data
         data, dispatch_mode = self._entry(args, kwargs)
         if self._skip(data):
             return data
