@@ -476,6 +476,31 @@ class ValueEstimatorBase(nn.Module, metaclass=abc.ABCMeta):
         data.set(self.tensor_keys.value_target, value_target)
         return (adv, value_target) if dispatch_mode else data
 
+    def _plain_inputs(self, data):
+        """``(dict, value, next_value, reward, done, terminated, advantage key, value_target key)`` of a :class:`RolloutData` in the
+        plain layout -- string keys, values already stored, unnamed dims, no ``steps_to_next_obs``, nothing that would record a
+        graph -- read with plain dict look-ups; None when it is anything else (the caller then goes the long way, which also
+        raises what is to be raised).  Lets the modules' ``forward`` cost less than the launch it issues."""
+        tk = self._tensor_keys
+        if tk is None:
+            tk = self.tensor_keys
+        vk, rk, dk, tmk, ak, vtk, sk = tk.value, tk.reward, tk.done, tk.terminated, tk.advantage, tk.value_target, tk.steps_to_next_obs
+        d = data._d
+        nxt = d.get("next")
+        if (nxt.__class__ is not dict or vk.__class__ is not str or rk.__class__ is not str or dk.__class__ is not str
+                or tmk.__class__ is not str or ak.__class__ is not str or vtk.__class__ is not str or sk.__class__ is not str or sk in d):
+            return None
+        names = data.names
+        if len(data.batch_size) < 1 or names.count(None) != len(names):
+            return None
+        try:
+            value, next_value, reward, done = d[vk], nxt[vk], nxt[rk], nxt[dk]
+            if torch.is_grad_enabled() and (value.requires_grad or next_value.requires_grad or reward.requires_grad):
+                return None
+        except (KeyError, TypeError, AttributeError):
+            return None
+        return d, value, next_value, reward, done, nxt.get(tmk, done), ak, vtk
+
     def _skip(self, data) -> bool:
         return bool(self.skip_existing) and all(data.get(k, None) is not None for k in self.out_keys)
 
@@ -535,26 +560,12 @@ class GAE(ValueEstimatorBase):
         return gamma, lmbda, value, next_value, reward, done, terminated, self._get_time_dim(time_dim, data)
 
     def _short_forward(self, data):
-        """The whole of ``forward`` for the plain case -- a :class:`RolloutData` with string keys that already holds the values,
-        scalar ``gamma`` / ``lmbda`` buffers, nothing to differentiate, no ranks: six dict look-ups and one hop to the C ABI, so that the
-        call costs less than the launch it issues.  None: not that case (``forward`` goes the long way and raises what is to be raised)."""
-        tk = self._tensor_keys
-        if tk is None:
-            tk = self.tensor_keys
-        vk, rk, dk, tmk, ak, vtk, sk = tk.value, tk.reward, tk.done, tk.terminated, tk.advantage, tk.value_target, tk.steps_to_next_obs
-        d = data._d
-        nxt = d.get("next")
-        if (nxt.__class__ is not dict or vk.__class__ is not str or rk.__class__ is not str or dk.__class__ is not str
-                or tmk.__class__ is not str or ak.__class__ is not str or vtk.__class__ is not str or sk.__class__ is not str or sk in d):
+        """The whole of ``forward`` for the plain case (``_plain_inputs``) with scalar ``gamma`` / ``lmbda`` buffers: one hop to the
+        C ABI.  None: not that case."""
+        got = self._plain_inputs(data)
+        if got is None:
             return None
-        names = data.names
-        if len(data.batch_size) < 1 or names.count(None) != len(names):
-            return None
-        try:
-            value, next_value, reward, done = d[vk], nxt[vk], nxt[rk], nxt[dk]
-            terminated = nxt.get(tmk, done)
-        except (KeyError, TypeError):
-            return None
+        d, value, next_value, reward, done, terminated, ak, vtk = got
         buffers = self._buffers
         g, lm = buffers["gamma"], buffers["lmbda"]
         c = self._short_coef
@@ -563,11 +574,6 @@ class GAE(ValueEstimatorBase):
             c = self._short_coef = (g, lm, g._version, lm._version, torch.get_default_dtype(), coef)
         coef = c[5]
         if coef is None:
-            return None
-        try:
-            if torch.is_grad_enabled() and (value.requires_grad or next_value.requires_grad or reward.requires_grad):
-                return None
-        except AttributeError:
             return None
         out = F._gae_fast(coef, None, value, next_value, reward, done, terminated, 1e-4 if self.average_gae else None, F.ALGO_AUTO,
                           len(data.batch_size) - 1)
@@ -631,28 +637,13 @@ class TDLambdaEstimator(ValueEstimatorBase):
         self._lmbda_one = False
 
     def _short_forward(self, data):
-        """``forward`` for the plain case (see ``GAE._short_forward``): dict look-ups, the buffers as python floats where those
-        act exactly like the buffers, the return estimate through the one-hop host path.  None: not that case."""
-        tk = self._tensor_keys
-        if tk is None:
-            tk = self.tensor_keys
-        vk, rk, dk, tmk, ak, vtk, sk = tk.value, tk.reward, tk.done, tk.terminated, tk.advantage, tk.value_target, tk.steps_to_next_obs
-        d = data._d
-        nxt = d.get("next")
-        if (nxt.__class__ is not dict or vk.__class__ is not str or rk.__class__ is not str or dk.__class__ is not str
-                or tmk.__class__ is not str or ak.__class__ is not str or vtk.__class__ is not str or sk.__class__ is not str or sk in d):
+        """``forward`` for the plain case (``_plain_inputs``): the buffers as python floats where those act exactly like the
+        buffers, the return estimate through the one-hop host path.  None: not that case."""
+        got = self._plain_inputs(data)
+        if got is None:
             return None
-        names = data.names
-        if len(data.batch_size) < 1 or names.count(None) != len(names):
-            return None
-        try:
-            value, next_value, reward, done = d[vk], nxt[vk], nxt[rk], nxt[dk]
-            terminated = nxt.get(tmk, done)
-            if torch.is_grad_enabled() and (value.requires_grad or next_value.requires_grad or reward.requires_grad):
-                return None
-            dt = next_value.dtype
-        except (KeyError, TypeError, AttributeError):
-            return None
+        d, value, next_value, reward, done, terminated, ak, vtk = got
+        dt = next_value.dtype
         buffers = self._buffers
         gamma = buffers["gamma"]
         if gamma.numel() != 1 or (self.vectorized and torch.promote_types(dt, gamma.dtype) != dt):
