@@ -5,6 +5,7 @@ rows, interleaved, lock-step, SEQ), time_dim anywhere, float32 / float64, coeffi
 per-element tensor), mask regimes (none, sparse, dense, all done, terminated not a subset of done, per-step masks expanded
 over the feature dims), the forward functions the path names.  Every case goes through the C ABI under AUTO dispatch and is
 compared with oracle/value_oracle.c at the SCAN bar (fp32 rtol = atol = 1e-5, fp64 1e-12; V-trace fp64 1e-11 for exp)."""
+import os
 import random
 
 import pytest
@@ -15,13 +16,15 @@ from torchrl_amd.objectives.value import functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-N_CASES = 500
+# TRL_FUZZ_SCALE=k (an occasional long run on the GPU box): k times as many cases of every sweep, on seeds beyond the default ones
+SCALE = max(1, int(os.environ.get("TRL_FUZZ_SCALE", "1")))
+N_CASES = 500 * SCALE
 
 
 def _case(seed):
     rng = random.Random(seed)
     nd = rng.choice([2, 3, 3, 3, 4])
-    T = rng.choice([1, 2, 3, 7, 16, 31, 32, 33, 64, 100, 128, 255, 256, 257, 300, 511, 1024, 1025, 2500, 4100])
+    T = rng.choice([1, 2, 3, 7, 16, 31, 32, 33, 64, 80, 100, 128, 200, 255, 256, 257, 300, 511, 1024, 1025, 2500, 4100])
     feat_choices = [1, 1, 1, 2, 3, 4, 5, 8, 9, 16, 33, 70]
     budget = 60000  # elements: the oracle side stays fast
     if nd == 2:
@@ -138,7 +141,7 @@ def test_random_case_against_oracle(seed):
         torch.testing.assert_close(vs.cpu().to(ea.dtype), evs, msg=lambda m: f"{info}: {m}", **vtol)
 
 
-N_BWD = 240
+N_BWD = 240 * SCALE
 
 
 @pytest.mark.parametrize("seed", range(N_BWD))
@@ -189,7 +192,7 @@ def test_random_backward_adjoint_identity(seed):
     assert rel < (2e-5 if dt == torch.float32 else 1e-12), f"{fn} {c}: <g,F(u)>={lhs.item()} <F^T g,u>={rhs.item()} rel={rel.item()} [{F.last_bwd_kernel()}]"
 
 
-N_SEQ = 300
+N_SEQ = 300 * SCALE
 
 
 @pytest.mark.parametrize("seed", range(N_SEQ))
