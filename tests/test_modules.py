@@ -20,6 +20,51 @@ def _kw(cls):
 
 
 # ------------------------------------------------------------------------------------------- CPU
+def _net_data(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    obs, nobs = torch.randn(3, 6, 3, generator=g), torch.randn(3, 6, 3, generator=g)
+    term = torch.rand(3, 6, 1, generator=g) < 0.1
+    return RolloutData({"obs": obs, "next": {"obs": nobs, "reward": torch.randn(3, 6, 1, generator=g), "done": term.clone(),
+                                             "terminated": term}}, batch_size=[3, 6])
+
+
+@pytest.mark.parametrize("cls", [GAE, TDLambdaEstimator, TD0Estimator])
+def test_functional_params_as_a_name_to_tensor_mapping(cls):
+    """advantages.py:425-516 with ``params`` / ``target_params``: without the tensordict package a mapping in
+    ``named_parameters()`` naming is applied with ``torch.func.functional_call``; the network's own parameters stay untouched and
+    receive no graph; ``params`` alone also serves the t+1 call; the reference's two ValueErrors."""
+    net = KeyedModule(nn.Linear(3, 1), ["obs"], ["state_value"])
+    m = cls(**_kw(cls), value_network=net) if "value_network" not in _kw(cls) else cls(**{**_kw(cls), "value_network": net})
+    p = {"module.weight": torch.full((1, 3), 0.5), "module.bias": torch.tensor([0.25], requires_grad=True)}
+    tp = {"module.weight": torch.full((1, 3), -1.0), "module.bias": torch.tensor([2.0])}
+    own = [q.detach().clone() for q in net.parameters()]
+    d = _net_data()
+    m(d, params=p)
+    lin = lambda x, w: x @ w["module.weight"].T + w["module.bias"]
+    torch.testing.assert_close(d.get("state_value"), lin(d.get("obs"), p).detach())
+    torch.testing.assert_close(d.get(("next", "state_value")), lin(d.get(("next", "obs")), p).detach())
+    assert not d.get("state_value").requires_grad and not d.get("advantage").requires_grad
+    d2 = _net_data()
+    m(d2, params=p, target_params=tp)
+    torch.testing.assert_close(d2.get("state_value"), lin(d2.get("obs"), p).detach())
+    torch.testing.assert_close(d2.get(("next", "state_value")), lin(d2.get(("next", "obs")), tp))
+    assert not torch.equal(d2.get("advantage"), d.get("advantage"))
+    d3 = _net_data()
+    m(d3)                                                   # the network's own parameters: untouched by the calls above
+    assert all(torch.equal(a, b) for a, b in zip(own, net.parameters()))
+    assert not torch.equal(d3.get("state_value"), d.get("state_value"))
+    with pytest.raises(ValueError, match="either both provided or not"):
+        m(_net_data(), target_params=tp)
+    sh = cls(**{**_kw(cls), "value_network": net, "shifted": True})
+    with pytest.raises(ValueError, match="single call"):
+        sh(_net_data(), params=p, target_params=tp)
+    d4 = _net_data()
+    sh(d4, params=p)                                        # one call on T + 1 steps with the same mapping
+    torch.testing.assert_close(d4.get("state_value"), lin(d4.get("obs"), p).detach())
+    with pytest.raises(NotImplementedError, match="functional parameters"):
+        m(_net_data(), params=[1, 2])
+
+
 @pytest.mark.parametrize("cls", ALL)
 def test_set_keys_and_deprecated_ctor_keys(cls):
     m = cls(**_kw(cls))

@@ -26,6 +26,7 @@ Differences that are deliberate:
 from __future__ import annotations
 
 import abc
+from collections.abc import Mapping
 import warnings
 from dataclasses import asdict, dataclass
 from typing import Callable, Optional, Tuple, Union
@@ -386,12 +387,12 @@ class ValueEstimatorBase(nn.Module, metaclass=abc.ABCMeta):
         network once on the T+1 steps ``[data, last step of data["next"]]``; otherwise it is called on
         ``data`` and on ``data["next"]`` (the reference vmaps the two calls; the result is the same)."""
         net = self.value_network
-        if params is not None or next_params is not None:
-            if not hasattr(params, "to_module"):
-                raise NotImplementedError("functional parameters need the tensordict package (params.to_module)")
         in_keys = list(getattr(net, "in_keys", []))
         nxt = data.get("next")
         if single_call:
+            if next_params is not None and next_params is not params:
+                raise ValueError("the value at t and t+1 cannot be retrieved in a single call without recurring to vmap when both "
+                                 "params and next params are passed.")
             ndim = None
             if data._has_names():
                 for i, name in enumerate(data.names):
@@ -411,6 +412,8 @@ class ValueEstimatorBase(nn.Module, metaclass=abc.ABCMeta):
             value_est = out.get(value_key) if _is_collection(out) else out
             value, value_ = value_est.narrow(tdim, 0, T), value_est.narrow(tdim, 1, T)
         else:
+            if (params is not None) ^ (next_params is not None):
+                raise ValueError("params and next_params must be either both provided or not.")
             out = self._run_net(net, data, params)
             value = out.get(value_key) if _is_collection(out) else out
             nxt_in = nxt if _is_collection(nxt) else data.get("next")
@@ -424,17 +427,32 @@ class ValueEstimatorBase(nn.Module, metaclass=abc.ABCMeta):
 
     @staticmethod
     def _run_net(net, data, params):
-        if params is not None:
+        """``net(data)`` under functional parameters: a tensordict of parameters (``params.to_module``, the reference's form,
+        advantages.py:485-489) or -- without the tensordict package -- a mapping ``name -> tensor`` in ``net.named_parameters()``
+        naming, applied with ``torch.func.functional_call``."""
+        if params is None:
+            return net(data)
+        if hasattr(params, "to_module"):
             with params.to_module(net):
                 return net(data)
-        return net(data)
+        if isinstance(params, Mapping) and isinstance(net, nn.Module):
+            return torch.func.functional_call(net, dict(params), (data,))
+        raise NotImplementedError("functional parameters: a tensordict of parameters (params.to_module) or, for an nn.Module value "
+                                  "network, a mapping name -> tensor")
 
     def _values(self, data, params, target_params):
         if self.value_network is not None:
             if params is not None:
-                params = params.detach()
-                if target_params is None:
-                    target_params = params.clone(False)
+                if hasattr(params, "to_module"):
+                    params = params.detach()
+                    if target_params is None:
+                        target_params = params.clone(False)
+                elif isinstance(params, Mapping):
+                    params = {k: v.detach() for k, v in params.items()}
+                    if target_params is None:
+                        target_params = params
+                else:
+                    self._run_net(self.value_network, data, params)  # raises: not a form of functional parameters
             req = [p.requires_grad for p in self._net_params()] if (params is None and target_params is None) else None
             try:
                 if req is not None:  # hold_out_net: no grads are assigned to the value net's params
