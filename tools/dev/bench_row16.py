@@ -8,10 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from torchrl_amd.objectives.value import functional as F  # noqa: E402
 from tools.bench_configs import inputs, timeit  # noqa: E402
 
-SHAPES32 = [(torch.float32, s_) for s_ in ((8192, 64, 4, 1), (8192, 128, 4, 1), (8192, 32, 8, 1), (8192, 50, 5, 1), (8192, 40, 3, 1), (8192, 20, 7, 1),
-                                            (4096, 100, 3, 1), (8192, 60, 6, 1), (4096, 127, 3, 1), (4096, 33, 5, 1), (4096, 99, 3, 1), (8192, 16, 16, 1),
-                                            (8192, 10, 2, 1), (65536, 8, 3, 1), (4096, 200, 4, 1), (8192, 48, 4, 1))] \
-    + [(torch.float64, s_) for s_ in ((8192, 64, 4, 1), (8192, 50, 5, 1), (8192, 32, 8, 1), (8192, 40, 3, 1), (4096, 99, 3, 1), (8192, 24, 4, 1))]
+SHAPES32 = [(torch.float32, s_) for s_ in ((4096, 127, 3, 1), (4096, 99, 3, 1), (4096, 65, 7, 1), (4096, 33, 7, 1), (8192, 25, 5, 1), (4096, 201, 5, 1), (4096, 100, 5, 1))]
 for dt, shape in SHAPES32:
     r, v, nv, d, t, *_ = inputs(shape, dt, 0.01, mask_shape=shape[:2] + (1, 1))
     call = F._prepare_gae(0.9, 0.9, v, nv, r, d, t, -3)

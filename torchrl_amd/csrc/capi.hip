@@ -158,17 +158,11 @@ static bool prefer_lockstep(int val_dtype, int coef_dtype, int64_t T, int64_t I)
 // Transposing / lock-step us at every chunk fill (profiles/r03_gae_rows_as_dpp_rows.txt): [4096x80x5] 7.9 / 12.8, [4096x96x4]
 // 7.6 / 9.9, [8192x64x4] 8.1 / 10.1, [8192x40x3] 6.7 / 8.0, [8192x60x6] 15.4 / 22.3, [4096x136x7] 16.9 / 31.7, [4096x160x3]
 // 8.2 / 14.4, [4096x200x4] 15.8 / 17.8, [8192x48x4] 9.0 / 9.1; fp64 [8192x40x3] 8.3 / 12.7, [8192x24x4] 8.1 / 10.2, [4096x160x3]
-// 15.4 / 25.9, [4096x99x3] 12.4 / 16.9.  The exception: fp32 chunks that lose their 16-byte accesses (R*T*I not a multiple of
-// 4: [4096x127x3] 13.0 / 9.8, [4096x99x3] 11.8 / 9.4) stay with the rule above.
+// 15.4 / 25.9, [4096x99x3] 12.4 / 16.9; chunks whose starts are not 16-byte aligned too, since their full vectors became
+// single element-aligned accesses (scan_core.h vload_u): [4096x127x3] 8.7 / 9.9, [4096x99x3] 8.4 / 9.4, [4096x65x7] 8.2 / 17.5.
 static bool gae_prefers_transposing(int val_dtype, int coef_dtype, int64_t T, int64_t I) {
     if (val_dtype != coef_dtype || I < 2) return false;
-    const int64_t V = val_dtype == TRL_F32 ? 4 : 2, chunk = 256 * V;
-    if (T * I > chunk) return false;
-    int64_t R = chunk / (T * I), g = T * I, v = V;  // make_plan's rows per chunk (scan_impl.h)
-    while (v) { const int64_t t = g % v; g = v; v = t; }
-    const int64_t q = V / g;
-    if (R >= q) R -= R % q;
-    return val_dtype == TRL_F64 || (R * T * I) % V == 0;
+    return T * I <= 256 * (val_dtype == TRL_F32 ? 4 : 2);
 }
 
 // Outer rows too long for the transposing kernel, 9 <= I <= 31: lock-step groups or the SEQ walk (coalesced only

@@ -100,11 +100,71 @@ __device__ __forceinline__ void vstore(T *__restrict__ p, const T (&in)[V]) {
         }
     }
 }
+// The same two for a vector that is only ELEMENT-aligned (rows whose length breaks the 16-byte alignment of chunk / row
+// starts: T = 9999, 999, 31 ...).  gfx950 serves global accesses of any width from dword- (byte-) aligned addresses in the
+// unaligned access mode ROCm runs in, and the compiler emits one global_load_dwordx4 / global_store_dwordx4 for an
+// under-aligned vector type: one instruction per lane instead of V, at the price of some lanes straddling a cache line.
+// Measured (GAE, profiles/r03_unaligned_rows.txt): fp32 [1024x9999] 61.2 -> 38.3 us, [8192x999] 53.1 -> 41.3, [16384x301] 37.3 -> 30.0;
+// fp64 [1024x9999] 96.8 -> 76.3, [8192x999] 74.2 -> 57.7 (aligned neighbours: 37.5 / 37.7 / 26.8; 75.7 / 56.7).
+template <typename T, int V>
+constexpr bool vec_width_ok() {  // widths one (or a few 16-byte) access instruction(s) can take
+    constexpr int B = V * (int)sizeof(T);
+    return B == 1 || B == 2 || B == 4 || B == 8 || (B >= 16 && B % 16 == 0);
+}
+template <typename R, int A>
+struct UnderAligned;
+template <typename R>
+struct UnderAligned<R, 1> { typedef R type __attribute__((aligned(1))); };
+template <typename R>
+struct UnderAligned<R, 2> { typedef R type __attribute__((aligned(2))); };
+template <typename R>
+struct UnderAligned<R, 4> { typedef R type __attribute__((aligned(4))); };
+template <typename R>
+struct UnderAligned<R, 8> { typedef R type __attribute__((aligned(8))); };
+template <typename T, int V>
+__device__ __forceinline__ void vload_u(const T *__restrict__ p, T (&out)[V]) {
+    constexpr int B = V * (int)sizeof(T);
+    if constexpr (B <= 16) {
+        typedef typename RawT<B>::type R;
+        typedef typename UnderAligned<R, (int)alignof(T)>::type RU;
+        const R raw = *(const RU *)p;
+        __builtin_memcpy(out, &raw, B);
+    } else {
+        static_assert(B % 16 == 0, "vector width");
+        typedef typename UnderAligned<u32x4, (int)alignof(T)>::type RU;
+#pragma unroll
+        for (int k = 0; k < B / 16; ++k) {
+            const u32x4 raw = ((const RU *)p)[k];
+            __builtin_memcpy((char *)out + 16 * k, &raw, 16);
+        }
+    }
+}
+template <typename T, int V>
+__device__ __forceinline__ void vstore_u(T *__restrict__ p, const T (&in)[V]) {
+    constexpr int B = V * (int)sizeof(T);
+    if constexpr (B <= 16) {
+        typedef typename RawT<B>::type R;
+        typedef typename UnderAligned<R, (int)alignof(T)>::type RU;
+        R raw;
+        __builtin_memcpy(&raw, in, B);
+        __builtin_nontemporal_store(raw, (RU *)p);
+    } else {
+        typedef typename UnderAligned<u32x4, (int)alignof(T)>::type RU;
+#pragma unroll
+        for (int k = 0; k < B / 16; ++k) {
+            u32x4 raw;
+            __builtin_memcpy(&raw, (const char *)in + 16 * k, 16);
+            __builtin_nontemporal_store(raw, (RU *)p + k);
+        }
+    }
+}
+// VEC: the launcher established that every full vector is 16-byte aligned; otherwise full vectors are element-aligned
 template <bool VEC, typename T, int V>
 __device__ __forceinline__ void load_n(const T *__restrict__ p, i64 flat, int nvalid, T (&out)[V]) {
-    if constexpr (VEC) {
+    if constexpr (VEC || vec_width_ok<T, V>()) {
         if (nvalid == V) {
-            vload<T, V>(p + flat, out);
+            if constexpr (VEC) vload<T, V>(p + flat, out);
+            else vload_u<T, V>(p + flat, out);
             return;
         }
     }
@@ -113,9 +173,10 @@ __device__ __forceinline__ void load_n(const T *__restrict__ p, i64 flat, int nv
 }
 template <bool VEC, typename T, int V>
 __device__ __forceinline__ void store_n(T *__restrict__ p, i64 flat, int nvalid, const T (&in)[V]) {
-    if constexpr (VEC) {
+    if constexpr (VEC || vec_width_ok<T, V>()) {
         if (nvalid == V) {
-            vstore<T, V>(p + flat, in);
+            if constexpr (VEC) vstore<T, V>(p + flat, in);
+            else vstore_u<T, V>(p + flat, in);
             return;
         }
     }
@@ -130,10 +191,11 @@ __device__ __forceinline__ void store_n(T *__restrict__ p, i64 flat, int nvalid,
 // consecutive elements per instruction.
 template <bool VEC, typename T, int V>
 __device__ __forceinline__ void load_n_rev(const T *__restrict__ p, i64 n_total, i64 flat, int nvalid, T (&out)[V]) {
-    if constexpr (VEC) {
+    if constexpr (VEC || vec_width_ok<T, V>()) {
         if (nvalid == V) {
             T tmp[V];
-            vload<T, V>(p + (n_total - flat - V), tmp);
+            if constexpr (VEC) vload<T, V>(p + (n_total - flat - V), tmp);
+            else vload_u<T, V>(p + (n_total - flat - V), tmp);
 #pragma unroll
             for (int e = 0; e < V; ++e) out[e] = tmp[V - 1 - e];
             return;
@@ -144,12 +206,13 @@ __device__ __forceinline__ void load_n_rev(const T *__restrict__ p, i64 n_total,
 }
 template <bool VEC, typename T, int V>
 __device__ __forceinline__ void store_n_rev(T *__restrict__ p, i64 n_total, i64 flat, int nvalid, const T (&in)[V]) {
-    if constexpr (VEC) {
+    if constexpr (VEC || vec_width_ok<T, V>()) {
         if (nvalid == V) {
             T tmp[V];
 #pragma unroll
             for (int e = 0; e < V; ++e) tmp[e] = in[V - 1 - e];
-            vstore<T, V>(p + (n_total - flat - V), tmp);
+            if constexpr (VEC) vstore<T, V>(p + (n_total - flat - V), tmp);
+            else vstore_u<T, V>(p + (n_total - flat - V), tmp);
             return;
         }
     }
@@ -163,7 +226,7 @@ __device__ __forceinline__ void store_n_rev(T *__restrict__ p, i64 n_total, i64 
 // does not know this asm is such a store (it may overwrite the registers with the very next instruction).
 template <bool VEC, typename T, int V>
 __device__ __forceinline__ void store_wt(T *__restrict__ p, i64 flat, int nvalid, const T (&in)[V]) {
-    if constexpr (VEC && V * sizeof(T) == 16) {
+    if constexpr (V * sizeof(T) == 16) {  // any element-aligned address (see vload_u)
         if (nvalid == V) {
             u32x4 raw;
             __builtin_memcpy(&raw, in, 16);
