@@ -182,6 +182,41 @@ def test_hip_ungrouped_one_launch(n, offset, kernel, dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_c_abi_standardize_in_place(dtype):
+    """include/trl_value.h: `out may alias x` for trl_standardize / trl_standardize_grouped -- on the one-launch routes (every
+    load precedes the gather), the small kernel and the two-launch route alike: bit-equal to the out-of-place call."""
+    from torchrl_amd import _extension as E
+    from torchrl_amd import _utils as U
+    from torchrl_amd.objectives.value import functional as F
+
+    lib = E.get_lib()
+    dev = torch.device("cuda:0")
+    code = 0 if dtype == torch.float32 else 1
+    for n, kernel in ((1000, "standardize_small"), (700001, "standardize_persistent"), (30000000, "normalize")):
+        x = _big((n,), dtype).to(dev)
+        ws = F._workspace(lib, dev, n, 1, 1)
+        out = torch.empty_like(x)
+        E.check(lib.trl_standardize(F._stream(dev), code, x.data_ptr(), n, 1e-6, out.data_ptr(), None, ws.data_ptr(), ws.numel()), lib)
+        assert F.last_kernel() == kernel
+        y = x.clone()
+        E.check(lib.trl_standardize(F._stream(dev), code, y.data_ptr(), n, 1e-6, y.data_ptr(), None, ws.data_ptr(), ws.numel()), lib)
+        assert torch.equal(y, out), (n, kernel)
+    for (outer, G, inner), kernel in (((40960, 5, 1), "standardize_grouped_persistent"), ((3000, 7, 11), "standardize_grouped_persistent"),
+                                      ((2000, 40, 3), "normalize_grouped")):
+        x = _big((outer, G, inner), dtype).to(dev)
+        st, wsp, wsn = U._scratch(lib, dev, F._stream(dev), outer, G, inner)
+        out = torch.empty_like(x)
+        args = lambda src, dst: (F._stream(dev), code, src.data_ptr(), outer, G, inner, 1e-6, dst.data_ptr(), st.data_ptr(), wsp, wsn)
+        E.check(lib.trl_standardize_grouped(*args(x, out)), lib)
+        assert F.last_kernel() == kernel
+        y = x.clone()
+        E.check(lib.trl_standardize_grouped(*args(y, y)), lib)
+        assert torch.equal(y, out), (outer, G, inner)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
 def test_one_launch_routes_share_the_workspace_with_the_fused_gae_step():
     """`_standardize(x)` of a large tensor and the single-launch GAE + normalise use the same {epoch, slots} header of the
     stream's workspace: 300 interleaved calls (more than the 8-bit tag's period) stay bit-identical to the first."""

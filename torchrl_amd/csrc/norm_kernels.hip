@@ -287,7 +287,7 @@ __device__ __forceinline__ void store_wt_vec16(void *p, const VT &v) {
 }
 
 template <typename TS, int K, int V>
-__global__ __launch_bounds__(kPnThreads) void standardize_persistent_kernel(const TS *__restrict__ x, TS *__restrict__ out, PnGeom geo,
+__global__ __launch_bounds__(kPnThreads) void standardize_persistent_kernel(const TS *x, TS *out, PnGeom geo,  // out may alias x (every load precedes the gather)
                                                                             gather::Header *ws, double *__restrict__ stats_out) {
     typedef TS vec_t __attribute__((ext_vector_type(V)));
     __shared__ double part[2 * kPnThreads];
