@@ -164,6 +164,22 @@ static bool gae_prefers_transposing(int val_dtype, int coef_dtype, int64_t T, in
     if (val_dtype != coef_dtype || I < 2) return false;
     return T * I <= 256 * (val_dtype == TRL_F32 ? 4 : 2);
 }
+// TD(lambda) / TD(1) take the same kernel (policies TdLambdaTurn / Td1Turn).  TD(lambda), transposing / lock-step us
+// (profiles/r03_interleaved_other_ops.txt): [4096x100x5] 8.8 / 11.4, [4096x80x5] 8.6 / 9.5, [8192x64x4] 8.4 / 9.8, [4096x136x7]
+// 13.3 / 26.7, [4096x200x4] 14.0 / 16.5, [8192x128x4] 15.1 / 17.0, [8192x100x3] 10.9 / 12.9, fp64 [4096x100x5] 12.7 / 23.0,
+// [8192x40x3] 8.8 / 10.7, [4096x99x3] 12.6 / 13.6 -- but the lock-step kernels below 75 % chunk fill at fp32: [8192x60x6]
+// 15.9 / 13.3, [4096x127x3] 9.1 / 8.4.
+static bool td_prefers_transposing(int val_dtype, int coef_dtype, int64_t T, int64_t I) {
+    if (val_dtype != coef_dtype || I < 2) return false;
+    const int64_t V = val_dtype == TRL_F32 ? 4 : 2, chunk = 256 * V;
+    if (T * I > chunk) return false;
+    if (val_dtype == TRL_F64) return true;
+    int64_t R = chunk / (T * I), g = T * I, v = V;  // make_plan's rows per chunk (scan_impl.h)
+    while (v) { const int64_t t = g % v; g = v; v = t; }
+    const int64_t q = V / g;
+    if (R >= q) R -= R % q;
+    return R * T * I * 100 >= chunk * 75;
+}
 
 // Outer rows too long for the transposing kernel, 9 <= I <= 31: lock-step groups or the SEQ walk (coalesced only
 // over i, but every (o, i) row is a lane).  Measured fp32 (SEQ / LOCKSTEP us): [64x1000x16] 381 / 20, [1024x300x16]
@@ -453,7 +469,7 @@ int trl_td_lambda_fwd(void *stream, int val_dtype, int coef_dtype, const void *r
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td_lambda_fwd: unknown algo %d", algo);
     size_t lb_bytes = 0;
     void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
-    if (rolling_gamma && algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I))
+    if (rolling_gamma && algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I) && !td_prefers_transposing(val_dtype, coef_dtype, T, I))
         res = launch_td_lambda_lockstep(s, val_dtype, coef_dtype, a);
     if (res.status == TRL_ERR_UNSUPPORTED && rolling_gamma && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN))
         res = launch_td_lambda_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
@@ -488,7 +504,7 @@ int trl_td1_fwd(void *stream, int val_dtype, int coef_dtype, const void *reward,
         return fail(TRL_ERR_INVALID_ARGUMENT, "trl_td1_fwd: unknown algo %d", algo);
     size_t lb_bytes = 0;
     void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
-    if (rolling_gamma && algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I))
+    if (rolling_gamma && algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I) && !td_prefers_transposing(val_dtype, coef_dtype, T, I))
         res = launch_td1_lockstep(s, val_dtype, coef_dtype, a);
     if (res.status == TRL_ERR_UNSUPPORTED && rolling_gamma && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN))
         res = launch_td1_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);

@@ -8,6 +8,9 @@
 // -- 16 B of LDS traffic per element and direction instead of 44, a third of the LDS footprint (12.7 KB per block) and far
 // fewer live registers, so twice as many blocks are resident.  C3 [4096 x 100 x 5]: 13.1 -> 9.8 us.
 // Same arithmetic as every other family: the lane replays its steps with delta + x*disc from its carry-in.
+// Round 3: the estimator-specific parts are policies (GaeTurn, TdLambdaTurn, Td1Turn): TD(lambda) / TD(1) returns with rolling
+// gamma take the same route -- C3-shaped TD(lambda) 11.1 -> 8.8 us, [4096x136x7] 18.3 -> 13.3, fp64 C3 17.6 -> 12.7 against the
+// generic transposing kernel of scan_impl.h, which keeps V-trace (its outputs need the next step's x and value).
 #pragma once
 #include "scan_impl.h"
 
@@ -24,6 +27,133 @@ struct GaePreparedOp {  // what scan_chunk needs of an estimator whose per-step 
     __device__ __forceinline__ TC step(int e, TC x) const { return delta[e] + x * disc[e]; }
     __device__ __forceinline__ void affine(int e, TC &a, TC &b) const { a = disc[e]; b = delta[e]; }
     __device__ __forceinline__ TS first_value() const { return (TS)0; }
+};
+
+// ---- what the kernel needs of an estimator -----------------------------------------------------------------------------
+// The kernel forms the per-step maps x_t = delta_t + disc_t * x_{t+1} in MEMORY order and only those two arrays cross LDS; a
+// policy names the value tensors to load, forms (delta, disc) of one element from them and the element's two mask bytes, and
+// says what is written.  GAE: the reference's own per-step expression (the replay delta + x*disc IS its recurrence).
+template <typename TS_, typename TG_>
+struct GaeTurn {
+    typedef TS_ TS;
+    typedef TG_ TG;
+    typedef typename Promote<TS, TG>::type TC;
+    typedef GaeArgs Args;
+    static constexpr bool kSecondOutput = true;  // value_target = advantage + the state value the lane still holds
+    template <int V>
+    struct Raw {
+        TS r[V], v[V], nv[V];
+        TG g[V], lg[V];
+    };
+    const TS *__restrict__ rp, *__restrict__ vp, *__restrict__ nvp;
+    const TG *__restrict__ gtp, *__restrict__ lgp;
+    TG gs, ls, lgs;
+    __device__ __forceinline__ explicit GaeTurn(const Args &a)
+        : rp((const TS *)a.reward), vp((const TS *)a.value), nvp((const TS *)a.next_value), gtp((const TG *)a.gamma_t),
+          lgp((const TG *)a.lg_t), gs((TG)a.gamma), ls((TG)a.lmbda), lgs((TG)a.lg) {}
+    template <bool VEC, int V>
+    __device__ __forceinline__ void load(i64 flat, int nvalid, Raw<V> &w) const {
+        load_n<VEC>(rp, flat, nvalid, w.r);
+        load_n<VEC>(vp, flat, nvalid, w.v);
+        load_n<VEC>(nvp, flat, nvalid, w.nv);
+        if (gtp) load_n<VEC>(gtp, flat, nvalid, w.g);
+        if (lgp) load_n<VEC>(lgp, flat, nvalid, w.lg);
+    }
+    template <int V>
+    __device__ __forceinline__ void maps(const Raw<V> &w, int e, u8 d, u8 tm, bool, TC &delta, TC &disc) const {
+        const TG ge = gtp ? w.g[e] : gs;
+        const TG ce = lgp ? w.lg[e] : (gtp ? ls * ge : lgs);
+        const TG g_nt = ge * (TG)(tm ? 0 : 1);  // multiply, not select: as the reference
+        disc = (TC)(ce * (TG)(d ? 0 : 1));
+        delta = ((TC)w.r[e] + (TC)g_nt * (TC)w.nv[e]) - (TC)w.v[e];
+    }
+    template <int V>
+    __device__ __forceinline__ TS kept(const Raw<V> &w, int e) const { return w.v[e]; }
+    static __device__ __forceinline__ TS *out0(const Args &a) { return (TS *)a.advantage; }
+    static __device__ __forceinline__ TS *out1(const Args &a) { return (TS *)a.value_target; }
+};
+
+// TD(lambda) return, rolling gamma (scan_core.h TdLambdaOp: the same sub-expressions).  The maps are TdLambdaOp::affine; the
+// step that ends a row starts from the masked next value of that step, which folds into a constant map there: delta =
+// step(init), disc = 0.  The replay delta + x*disc is the recurrence re-associated: results differ from the exact-step kernels
+// by rounding only (SCAN bar); done positions stay bit-exact (disc = 0 there and delta is the reference's expression).
+template <typename TS_, typename TG_>
+struct TdLambdaTurn {
+    typedef TS_ TS;
+    typedef TG_ TG;
+    typedef typename Promote<TS, TG>::type TC;
+    typedef TdLambdaArgs Args;
+    static constexpr bool kSecondOutput = false;
+    template <int V>
+    struct Raw {
+        TS r[V], nv[V];
+        TG g[V], l[V];
+    };
+    const TS *__restrict__ rp, *__restrict__ nvp;
+    const TG *__restrict__ gtp, *__restrict__ ltp;
+    TG gs, ls;
+    __device__ __forceinline__ explicit TdLambdaTurn(const Args &a)
+        : rp((const TS *)a.reward), nvp((const TS *)a.next_value), gtp((const TG *)a.gamma_t), ltp((const TG *)a.lmbda_t),
+          gs((TG)a.gamma), ls((TG)a.lmbda) {}
+    template <bool VEC, int V>
+    __device__ __forceinline__ void load(i64 flat, int nvalid, Raw<V> &w) const {
+        load_n<VEC>(rp, flat, nvalid, w.r);
+        load_n<VEC>(nvp, flat, nvalid, w.nv);
+        if (gtp) load_n<VEC>(gtp, flat, nvalid, w.g);
+        if (ltp) load_n<VEC>(ltp, flat, nvalid, w.l);
+    }
+    template <int V>
+    __device__ __forceinline__ void maps(const Raw<V> &w, int e, u8 d, u8 tm, bool row_end, TC &delta, TC &disc) const {
+        const TG gm = gtp ? w.g[e] : gs, lm = ltp ? w.l[e] : ls;
+        const TS nvm = w.nv[e] * (TS)(tm ? 0 : 1), dn = (TS)(d ? 1 : 0), omd = (TS)(d ? 0 : 1);
+        const TG oml = (TG)1 - lm;
+        const TC g1 = row_end ? (TC)nvm * (TC)omd + (TC)(nvm * dn) : (TC)(nvm * dn);  // row end: step(init), init = nvm
+        delta = (TC)w.r[e] + (TC)gm * ((TC)oml * (TC)nvm + (TC)lm * g1);
+        disc = row_end ? (TC)0 : ((TC)gm * (TC)lm) * (TC)omd;
+    }
+    template <int V>
+    __device__ __forceinline__ TS kept(const Raw<V> &, int) const { return (TS)0; }
+    static __device__ __forceinline__ TS *out0(const Args &a) { return (TS *)a.returns; }
+    static __device__ __forceinline__ TS *out1(const Args &) { return nullptr; }
+};
+
+// TD(1) return, rolling gamma (scan_core.h Td1Op): starts from the RAW next value of the row's last step.
+template <typename TS_, typename TG_>
+struct Td1Turn {
+    typedef TS_ TS;
+    typedef TG_ TG;
+    typedef typename Promote<TS, TG>::type TC;
+    typedef TdLambdaArgs Args;
+    static constexpr bool kSecondOutput = false;
+    template <int V>
+    struct Raw {
+        TS r[V], nv[V];
+        TG g[V];
+    };
+    const TS *__restrict__ rp, *__restrict__ nvp;
+    const TG *__restrict__ gtp;
+    TG gs;
+    __device__ __forceinline__ explicit Td1Turn(const Args &a)
+        : rp((const TS *)a.reward), nvp((const TS *)a.next_value), gtp((const TG *)a.gamma_t), gs((TG)a.gamma) {}
+    template <bool VEC, int V>
+    __device__ __forceinline__ void load(i64 flat, int nvalid, Raw<V> &w) const {
+        load_n<VEC>(rp, flat, nvalid, w.r);
+        load_n<VEC>(nvp, flat, nvalid, w.nv);
+        if (gtp) load_n<VEC>(gtp, flat, nvalid, w.g);
+    }
+    template <int V>
+    __device__ __forceinline__ void maps(const Raw<V> &w, int e, u8 d, u8 tm, bool row_end, TC &delta, TC &disc) const {
+        const TG gnt = (gtp ? w.g[e] : gs) * (TG)(tm ? 0 : 1);
+        const bool b = d && !tm;
+        const TS dnt = (TS)(b ? 1 : 0), omdnt = (TS)(b ? 0 : 1);
+        const TC tail = row_end ? (TC)omdnt * (TC)w.nv[e] + (TC)(dnt * w.nv[e]) : (TC)(dnt * w.nv[e]);  // row end: step(init), init = nv
+        delta = (TC)w.r[e] + (TC)gnt * tail;
+        disc = row_end ? (TC)0 : (TC)gnt * (TC)omdnt;
+    }
+    template <int V>
+    __device__ __forceinline__ TS kept(const Raw<V> &, int) const { return (TS)0; }
+    static __device__ __forceinline__ TS *out0(const Args &a) { return (TS *)a.returns; }
+    static __device__ __forceinline__ TS *out1(const Args &) { return nullptr; }
 };
 
 // 4 blocks of 4 waves per CU and a grid of exactly that many blocks: with the next chunk's loads in flight a lane holds two
@@ -47,9 +177,10 @@ constexpr int kGilBlocksPerCu = 4;  // resident blocks per CU = the grid's block
 // lanes, 100 of 112 steps).  The memory-order phases (V elements per lane, 16-byte accesses) are the same.  Measured: C3 9.55 ->
 // 8.49 us back-to-back, 10.45 -> 9.28 us rocprofv3 average; [4096x112x3] 9.16 -> 8.08; fp64 C3 17.65 -> 16.6; LG = 32 (128 < T <=
 // 256): [4096x200x5] 19.4 -> 17.8, [4096x160x3] 9.55 -> 8.2, [4096x136x7] 18.7 -> 16.9, fp64 [4096x160x3] 16.5 -> 15.4.
-template <typename TS, typename TG, int V, int VR, int LG, bool VEC, bool WAVE_INDEP, bool PAD>
-__global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel(GaeArgs args, ScanGeom geo, int I, double *partials) {
-    typedef typename Promote<TS, TG>::type TC;
+template <class P, int V, int VR, int LG, bool VEC, bool WAVE_INDEP, bool PAD>
+__global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel(typename P::Args args, ScanGeom geo, int I, double *partials) {
+    typedef typename P::TS TS;
+    typedef typename P::TC TC;
     typedef GaePreparedOp<TS, TC, V> Op;
     constexpr int CH = kTeam * V;
     constexpr int CHP = CH + CH / 32;
@@ -66,6 +197,7 @@ __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel
     // in-chunk offset of each of the lane's V elements once the chunk is seen as rows (o, i) of T steps; mq: the step
     // (o, t) an element of the lane's MEMORY-order slice belongs to (masks shared by the I feature elements of a step)
     int pe[V], mq[V];
+    unsigned ends = 0u;  // bit e: element e of the lane's MEMORY-order slice is the last step of its row
     {
         unsigned rv = (unsigned)lane_off / T, t = (unsigned)lane_off % T;
         unsigned ol = rv / (unsigned)I, i = rv % (unsigned)I;
@@ -73,6 +205,7 @@ __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel
         for (int e = 0; e < V; ++e) {
             pe[e] = pad((int)((ol * T + t) * (unsigned)I + i));
             mq[e] = (int)((unsigned)(lane_off + e) / (unsigned)I);
+            if ((unsigned)mq[e] % T == T - 1u) ends |= 1u << e;
             if (++t == T) { t = 0; if (++i == (unsigned)I) { i = 0; ++ol; } }
         }
     }
@@ -89,17 +222,10 @@ __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel
         }
     }
     const bool bcast = args.mask_bcast != 0;
-    const TG gs = (TG)args.gamma, ls = (TG)args.lmbda, lgs = (TG)args.lg;
-    const TS *__restrict__ rp = (const TS *)args.reward;
-    const TS *__restrict__ vp = (const TS *)args.value;
-    const TS *__restrict__ nvp = (const TS *)args.next_value;
-    const TG *__restrict__ gtp = (const TG *)args.gamma_t;
-    const TG *__restrict__ lgp = (const TG *)args.lg_t;
-
+    const P pol(args);
     struct Raw {
-        TS r[V], v[V], nv[V];
+        typename P::template Raw<V> val;
         u8 d[V], tm[V];
-        TG g[V], lg[V];
     };
     auto geom_of = [&](i64 it, i64 &row0, i64 &start, int &count) {
         const i64 c = it * gridDim.x + blockIdx.x;
@@ -116,9 +242,7 @@ __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel
         geom_of(it, row0, start, count);
         const int nvalid = clamp_nvalid(count, lane_off, V);
         const i64 flat = start + lane_off;
-        load_n<VEC>(rp, flat, nvalid, w.r);
-        load_n<VEC>(vp, flat, nvalid, w.v);
-        load_n<VEC>(nvp, flat, nvalid, w.nv);
+        pol.template load<VEC>(flat, nvalid, w.val);
         if (bcast) {
             const i64 mstart = row0 * geo.T;
 #pragma unroll
@@ -131,8 +255,6 @@ __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel
             load_n<VEC>(args.done, flat, nvalid, w.d);
             load_n<VEC>(args.terminated, flat, nvalid, w.tm);
         }
-        if (gtp) load_n<VEC>(gtp, flat, nvalid, w.g);
-        if (lgp) load_n<VEC>(lgp, flat, nvalid, w.lg);
     };
 
     double s = 0.0, ss = 0.0;
@@ -146,24 +268,12 @@ __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel
         geom_of(it, row0, start, count);
         const int nvalid = clamp_nvalid(count, lane_off, V);
         const i64 flat = start + lane_off;
-        const TS(&r)[V] = cur.r;
-        const TS(&nv)[V] = cur.nv;
-        const u8(&d)[V] = cur.d;
-        const u8(&tm)[V] = cur.tm;
-        const TG(&g)[V] = cur.g;
-        const TG(&lg)[V] = cur.lg;
-        TS v[V];
+        TS v[V];  // what the second output adds to the first (GAE: the state value)
 #pragma unroll
-        for (int e = 0; e < V; ++e) v[e] = cur.v[e];
+        for (int e = 0; e < V; ++e) v[e] = pol.kept(cur.val, e);
         TC delta[V], disc[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            const TG ge = gtp ? g[e] : gs;
-            const TG ce = lgp ? lg[e] : (gtp ? ls * ge : lgs);
-            const TG g_nt = ge * (TG)(tm[e] ? 0 : 1);  // multiply, not select: as the reference
-            disc[e] = (TC)(ce * (TG)(d[e] ? 0 : 1));
-            delta[e] = ((TC)r[e] + (TC)g_nt * (TC)nv[e]) - (TC)v[e];
-        }
+        for (int e = 0; e < V; ++e) pol.maps(cur.val, e, cur.d[e], cur.tm[e], (ends >> e) & 1u, delta[e], disc[e]);
         {
             TC *dd = (TC *)__builtin_assume_aligned(ld_d + pad(lane_off), 16);
             TC *dc = (TC *)__builtin_assume_aligned(ld_c + pad(lane_off), 16);
@@ -235,7 +345,7 @@ __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel
                                    });
         }
         __syncthreads();
-        // ---- memory order again: value_target = advantage + v, coalesced stores ------------------------------------------
+        // ---- memory order again: (GAE) value_target = advantage + v, coalesced stores --------------------------------------
         {
             TS adv[V], vt[V];
             const TS *src = (const TS *)__builtin_assume_aligned(ld_o + pad(lane_off), 16);
@@ -244,8 +354,8 @@ __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel
                 adv[e] = src[e];
                 vt[e] = adv[e] + v[e];
             }
-            store_n<VEC>((TS *)args.advantage, flat, nvalid, adv);
-            store_n<VEC>((TS *)args.value_target, flat, nvalid, vt);
+            store_n<VEC>(P::out0(args), flat, nvalid, adv);
+            if constexpr (P::kSecondOutput) store_n<VEC>(P::out1(args), flat, nvalid, vt);
         }
         cur = nxt;
     }
@@ -258,8 +368,10 @@ __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel
     }
 }
 
-template <typename TS, typename TG, int V>
-LaunchResult launch_gae_interleaved(hipStream_t s, const GaeArgs &a, const Plan &p, int cus) {
+template <class P, int V>
+LaunchResult launch_turn(hipStream_t s, const typename P::Args &a, const Plan &p, int cus, double *partials, const char *name) {
+    typedef typename P::TS TS;
+    typedef typename P::TG TG;
     ScanGeom geo{a.O, a.T, p.rows_per_chunk, scan_lanes_for(a.T, V, p.wave_indep), p.nchunks};
     i64 nb = p.nchunks;
     if (nb > (i64)cus * kGilBlocksPerCu) nb = (i64)cus * kGilBlocksPerCu;
@@ -277,8 +389,8 @@ LaunchResult launch_gae_interleaved(hipStream_t s, const GaeArgs &a, const Plan 
     const dim3 grid((unsigned)nb);
 #define TRL_GIL(VR, LG, VEC, WI)                                                                                                \
     do {                                                                                                                        \
-        if (pad_lds) hipLaunchKernelGGL((gae_interleaved_kernel<TS, TG, V, VR, LG, VEC, WI, true>), grid, dim3(kTeam), 0, s, a, geo, (int)a.I, a.partials); \
-        else hipLaunchKernelGGL((gae_interleaved_kernel<TS, TG, V, VR, LG, VEC, WI, false>), grid, dim3(kTeam), 0, s, a, geo, (int)a.I, a.partials);         \
+        if (pad_lds) hipLaunchKernelGGL((gae_interleaved_kernel<P, V, VR, LG, VEC, WI, true>), grid, dim3(kTeam), 0, s, a, geo, (int)a.I, partials); \
+        else hipLaunchKernelGGL((gae_interleaved_kernel<P, V, VR, LG, VEC, WI, false>), grid, dim3(kTeam), 0, s, a, geo, (int)a.I, partials);         \
     } while (0)
 #define TRL_GIL_ROW(VR, LG) { if (p.vec) TRL_GIL(VR, LG, true, false); else TRL_GIL(VR, LG, false, false); }
 #define TRL_GIL_ROWS(LG)                          \
@@ -295,7 +407,22 @@ LaunchResult launch_gae_interleaved(hipStream_t s, const GaeArgs &a, const Plan 
 #undef TRL_GIL_ROWS
 #undef TRL_GIL_ROW
 #undef TRL_GIL
-    return LaunchResult{0, nb, "gae_scan_interleaved"};
+    return LaunchResult{0, nb, name};
+}
+
+template <typename TS, typename TG, int V>
+LaunchResult launch_gae_interleaved(hipStream_t s, const GaeArgs &a, const Plan &p, int cus) {
+    return launch_turn<GaeTurn<TS, TG>, V>(s, a, p, cus, a.partials, "gae_scan_interleaved");
+}
+
+template <typename TS, typename TG, int V>
+LaunchResult launch_td1_interleaved(hipStream_t s, const TdLambdaArgs &a, const Plan &p, int cus) {
+    return launch_turn<Td1Turn<TS, TG>, V>(s, a, p, cus, nullptr, "td1_scan_interleaved");
+}
+
+template <typename TS, typename TG, int V>
+LaunchResult launch_td_lambda_interleaved(hipStream_t s, const TdLambdaArgs &a, const Plan &p, int cus) {
+    return launch_turn<TdLambdaTurn<TS, TG>, V>(s, a, p, cus, nullptr, "td_lambda_scan_interleaved");
 }
 
 }  // namespace

@@ -46,6 +46,8 @@ LaunchResult launch_td_lambda_scan(hipStream_t s, int vdt, int cdt, const TdLamb
         typedef decltype(op) Op;
         Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus(), lb_ws ? lb_bytes : 0, false);
         if (!p.ok) return LaunchResult{2, 0, nullptr};
+        // I > 1: the kernel that forms the maps before the LDS turn (gae_interleaved.h), as GAE
+        if (p.interleaved) return launch_td_lambda_interleaved<typename Op::TS, typename Op::TG, Op::V>(s, a, p, device_cus());
         return launch_scan<Op>(s, a, p, a.O, a.T, a.I, nullptr,
                                p.interleaved ? "td_lambda_scan_interleaved" : p.lookback ? "td_lambda_scan_lookback" : p.long_rows ? "td_lambda_scan_long" : "td_lambda_scan_short", lb_ws);
     });
@@ -58,6 +60,7 @@ LaunchResult launch_td1_scan(hipStream_t s, int vdt, int cdt, const TdLambdaArgs
         typedef decltype(op) Op;
         Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus(), lb_ws ? lb_bytes : 0, false);
         if (!p.ok) return LaunchResult{2, 0, nullptr};
+        if (p.interleaved) return launch_td1_interleaved<typename Op::TS, typename Op::TG, Op::V>(s, a, p, device_cus());
         return launch_scan<Op>(s, a, p, a.O, a.T, a.I, nullptr,
                                p.interleaved ? "td1_scan_interleaved" : p.lookback ? "td1_scan_lookback" : p.long_rows ? "td1_scan_long" : "td1_scan_short", lb_ws);
     });
