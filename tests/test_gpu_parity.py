@@ -198,6 +198,58 @@ def test_multifeature_vs_oracle(shape, time_dim, dtype):
     check(adv, O.gae(0.9, 0.9, v, nv, r, done, term, time_dim=time_dim)[0], False, done)
 
 
+WIDE = [((5, 100, 20), -2), ((3, 100, 30), -2), ((7, 120, 13), -2), ((4, 200, 20), -2), ((9, 100, 11), -2), ((2, 100, 40), -2),
+        ((6, 150, 8), -2), ((11, 65, 33, 1), -3), ((3, 256, 9), -2), ((4, 129, 7, 2), 1), ((300, 100, 12), -2)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape,time_dim", WIDE, ids=["x".join(map(str, s)) for s, _ in WIDE])
+def test_many_feature_rows_on_wide_blocks(shape, time_dim, dtype):
+    """Outer rows of more than a team's chunk (256 * V elements) and at most 1024 * V, 64 < T <= 256 (MAPPO-shaped rollouts with
+    11 - 40 agents): GAE, TD(lambda) and TD(1) on the 1024-thread transposing kernel (gae_interleaved.h, NT = 1024), scalar and
+    per-element gamma, compact (expanded) masks, per-block moments; shapes it does not take fall through to LOCKSTEP / SEQ."""
+    r, v, nv, done, term, gam, lp, lm = _rand_inputs(shape, dtype, seed=31)
+    td = time_dim if time_dim < 0 else time_dim - len(shape)
+    T = shape[len(shape) + td]
+    I = 1
+    for k in shape[len(shape) + td + 1:]:
+        I *= k
+    V = 4 if dtype == torch.float32 else 2
+    lg = 16 if T <= 128 else 32
+    wide = 256 * V < T * I <= 1024 * V and 64 < T <= 256 and I != 16 and I <= 1024 // lg
+    mshape = tuple(shape[:len(shape) + td + 1]) + (1,) * (-td - 1)
+    g = torch.Generator().manual_seed(7)
+    term_c = torch.rand(mshape, generator=g) < 0.03
+    done_c = term_c | (torch.rand(mshape, generator=g) < 0.03)
+    for gamma in (0.9, gam):
+        for dn, tm, dd, tt in ((done, term, cu(done), cu(term)), (done_c.expand(shape), term_c.expand(shape), cu(done_c).expand(shape), cu(term_c).expand(shape))):
+            oadv, ovt = O.gae(gamma, 0.9, v, nv, r, dn, tm, time_dim=time_dim)
+            oret = O.td_lambda(gamma, 0.9, nv, r, dn, tm, time_dim=time_dim)
+            oret1 = O.td1(gamma, nv, r, dn, tm, time_dim=time_dim)
+            gcall = F._prepare_gae(cu(gamma), 0.9, cu(v), cu(nv), cu(r), dd, tt, time_dim)
+            tcall = F._prepare_td_lambda(cu(gamma), 0.9, cu(nv), cu(r), dd, tt, None, time_dim)
+            t1call = F._prepare_td1(cu(gamma), cu(nv), cu(r), dd, tt, True, time_dim)
+            for algo in ((F.ALGO_AUTO, SCAN) if wide else (F.ALGO_AUTO,)):
+                adv, vt, st = F._launch_gae(gcall, want_stats=True, algo=algo)
+                if wide:
+                    assert F.last_kernel() == "gae_scan_interleaved", F.last_kernel()
+                check(adv, oadv, False, dn)
+                check(vt, ovt, False, dn)
+                a64 = adv.double()
+                ref_st = torch.stack([torch.tensor(float(a64.numel()), device=DEV), a64.sum(), (a64 * a64).sum()])
+                torch.testing.assert_close(st, ref_st, rtol=1e-12, atol=1e-9)
+                ret = F._launch_td_lambda(tcall, dtype, algo=algo)
+                if wide:
+                    assert F.last_kernel() == "td_lambda_scan_interleaved", F.last_kernel()
+                check(ret, oret, False)
+                ret1 = F._launch_td1(t1call, dtype, algo=algo)
+                if wide:
+                    assert F.last_kernel() == "td1_scan_interleaved", F.last_kernel()
+                check(ret1, oret1, False)
+    nadv, _ = F.gae_normalized(0.9, 0.9, cu(v), cu(nv), cu(r), cu(done), cu(term), time_dim=time_dim)
+    torch.testing.assert_close(nadv.cpu(), O.normalize(O.gae(0.9, 0.9, v, nv, r, done, term, time_dim=time_dim)[0], 1e-4), rtol=1e-5, atol=1e-5)
+
+
 def test_successive_trajectories_equal_concatenation():
     """test_cost.py:14984-15135: a batch with a `terminated` at T//2-1 equals the two halves computed apart."""
     T = 64

@@ -161,8 +161,10 @@ static bool prefer_lockstep(int val_dtype, int coef_dtype, int64_t T, int64_t I)
 // 15.4 / 25.9, [4096x99x3] 12.4 / 16.9; chunks whose starts are not 16-byte aligned too, since their full vectors became
 // single element-aligned accesses (scan_core.h vload_u): [4096x127x3] 8.7 / 9.9, [4096x99x3] 8.4 / 9.4, [4096x65x7] 8.2 / 17.5.
 static bool gae_prefers_transposing(int val_dtype, int coef_dtype, int64_t T, int64_t I) {
-    if (val_dtype != coef_dtype || I < 2) return false;
-    return T * I <= 256 * (val_dtype == TRL_F32 ? 4 : 2);
+    (void)coef_dtype;  // python-float coefficients beside fp64 values are fp32: the common fp64 call
+    if (I < 2) return false;
+    if (T * I <= 256 * (val_dtype == TRL_F32 ? 4 : 2)) return true;
+    return scan_turn_big_ok(val_dtype, T, I);  // outer rows of up to 1024 * V elements: 1024-thread blocks (gae_interleaved.h)
 }
 // TD(lambda) / TD(1) take the same kernel (policies TdLambdaTurn / Td1Turn).  TD(lambda), transposing / lock-step us
 // (profiles/r03_interleaved_other_ops.txt): [4096x100x5] 8.8 / 11.4, [4096x80x5] 8.6 / 9.5, [8192x64x4] 8.4 / 9.8, [4096x136x7]
@@ -170,9 +172,10 @@ static bool gae_prefers_transposing(int val_dtype, int coef_dtype, int64_t T, in
 // [8192x40x3] 8.8 / 10.7, [4096x99x3] 12.6 / 13.6 -- but the lock-step kernels below 75 % chunk fill at fp32: [8192x60x6]
 // 15.9 / 13.3, [4096x127x3] 9.1 / 8.4.
 static bool td_prefers_transposing(int val_dtype, int coef_dtype, int64_t T, int64_t I) {
-    if (val_dtype != coef_dtype || I < 2) return false;
+    (void)coef_dtype;
+    if (I < 2) return false;
     const int64_t V = val_dtype == TRL_F32 ? 4 : 2, chunk = 256 * V;
-    if (T * I > chunk) return false;
+    if (T * I > chunk) return scan_turn_big_ok(val_dtype, T, I);
     if (val_dtype == TRL_F64) return true;
     int64_t R = chunk / (T * I), g = T * I, v = V;  // make_plan's rows per chunk (scan_impl.h)
     while (v) { const int64_t t = g % v; g = v; v = t; }

@@ -177,19 +177,23 @@ constexpr int kGilBlocksPerCu = 4;  // resident blocks per CU = the grid's block
 // lanes, 100 of 112 steps).  The memory-order phases (V elements per lane, 16-byte accesses) are the same.  Measured: C3 9.55 ->
 // 8.49 us back-to-back, 10.45 -> 9.28 us rocprofv3 average; [4096x112x3] 9.16 -> 8.08; fp64 C3 17.65 -> 16.6; LG = 32 (128 < T <=
 // 256): [4096x200x5] 19.4 -> 17.8, [4096x160x3] 9.55 -> 8.2, [4096x136x7] 18.7 -> 16.9, fp64 [4096x160x3] 16.5 -> 15.4.
-template <class P, int V, int VR, int LG, bool VEC, bool WAVE_INDEP, bool PAD>
-__global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel(typename P::Args args, ScanGeom geo, int I, double *partials) {
+// NT: threads per block.  256 (a team, 4 blocks per CU), or 1024 with a chunk of 1024 * V elements (round 3, row mapping only):
+// whole outer rows of up to 4096 fp32 elements -- MAPPO-shaped rollouts with 11 - 40 agents, which the lock-step kernels served
+// at 1.1 - 3.6 TB/s ([4096x100x30] 238 us, [4096x100x11] 59.5 us, [4096x100x20] 57.0 us).
+template <class P, int V, int VR, int LG, bool VEC, bool WAVE_INDEP, bool PAD, int NT = kTeam>
+__global__ __launch_bounds__(NT, kGilBlocksPerCu) void gae_interleaved_kernel(typename P::Args args, ScanGeom geo, int I, double *partials) {
     typedef typename P::TS TS;
     typedef typename P::TC TC;
     typedef GaePreparedOp<TS, TC, V> Op;
-    constexpr int CH = kTeam * V;
+    static_assert(NT == kTeam || VR > 0, "blocks wider than a team exist for the row mapping only");
+    constexpr int CH = NT * V;
     constexpr int CHP = CH + CH / 32;
     auto pad = [&](int p) { return PAD ? p + ((p >> 7) << 2) : p; };  // scan_impl.h: bank-conflict padding, 16-byte accesses kept
     __shared__ __align__(16) TC ld_d[CHP];
     __shared__ __align__(16) TC ld_c[CHP];
     __shared__ __align__(16) TS ld_o[CHP];
     __shared__ TeamShared<Op> sh;
-    __shared__ double red[2 * kWaves];
+    __shared__ double red[2 * (NT / kWave)];
     const int lane_off = (int)threadIdx.x * V;
     const unsigned T = (unsigned)geo.T;
     const i64 row_elems = geo.T * I;
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel
                     ss += (double)a * (double)a;
                 }
             }
-        } else {
+        } else if constexpr (NT == kTeam) {
         Op op;
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel
         cur = nxt;
     }
     if (partials) {
-        block_sum2<kTeam>(s, ss, red);
+        block_sum2<NT>(s, ss, red);
         if (threadIdx.x == 0) {
             partials[2 * (i64)blockIdx.x] = s;
             partials[2 * (i64)blockIdx.x + 1] = ss;
@@ -368,13 +372,14 @@ __global__ __launch_bounds__(kTeam, kGilBlocksPerCu) void gae_interleaved_kernel
     }
 }
 
-template <class P, int V>
+template <class P, int V, int NT = kTeam>
 LaunchResult launch_turn(hipStream_t s, const typename P::Args &a, const Plan &p, int cus, double *partials, const char *name) {
     typedef typename P::TS TS;
     typedef typename P::TG TG;
+    constexpr int kPerCu = NT == kTeam ? kGilBlocksPerCu : 1;  // resident blocks per CU (16 waves either way)
     ScanGeom geo{a.O, a.T, p.rows_per_chunk, scan_lanes_for(a.T, V, p.wave_indep), p.nchunks};
     i64 nb = p.nchunks;
-    if (nb > (i64)cus * kGilBlocksPerCu) nb = (i64)cus * kGilBlocksPerCu;
+    if (nb > (i64)cus * kPerCu) nb = (i64)cus * kPerCu;
     if (nb > 4096) nb = 4096;  // per-block partials: scan_max_partials
     typedef typename Promote<TS, TG>::type TC;
     // rows as 16- / 32-lane groups (VR steps per lane) when T does not tile a wave anyway: 64 < T <= 128 / 128 < T <= 256
@@ -383,14 +388,15 @@ LaunchResult launch_turn(hipStream_t s, const typename P::Args &a, const Plan &p
     if (!p.wave_indep && a.T > 64 && a.T <= 128) lg = 16;
     if (!p.wave_indep && a.T > 128 && a.T <= 256) lg = 32;
     const int vr = lg ? (int)((a.T + lg - 1) / lg) : 0;
-    const bool rowmap = lg != 0 && rows <= kTeam / lg && vr >= 5 && vr <= 8;
+    const bool rowmap = lg != 0 && rows <= NT / lg && vr >= 5 && vr <= 8;
+    if (NT != kTeam && !rowmap) return LaunchResult{2, 0, nullptr};
     const i64 stride_words = (i64)(rowmap ? vr : V) * a.I * (i64)(sizeof(TC) / 4);
     const bool pad_lds = stride_words % 8 == 0;
     const dim3 grid((unsigned)nb);
 #define TRL_GIL(VR, LG, VEC, WI)                                                                                                \
     do {                                                                                                                        \
-        if (pad_lds) hipLaunchKernelGGL((gae_interleaved_kernel<P, V, VR, LG, VEC, WI, true>), grid, dim3(kTeam), 0, s, a, geo, (int)a.I, partials); \
-        else hipLaunchKernelGGL((gae_interleaved_kernel<P, V, VR, LG, VEC, WI, false>), grid, dim3(kTeam), 0, s, a, geo, (int)a.I, partials);         \
+        if (pad_lds) hipLaunchKernelGGL((gae_interleaved_kernel<P, V, VR, LG, VEC, WI, true, NT>), grid, dim3(NT), 0, s, a, geo, (int)a.I, partials); \
+        else hipLaunchKernelGGL((gae_interleaved_kernel<P, V, VR, LG, VEC, WI, false, NT>), grid, dim3(NT), 0, s, a, geo, (int)a.I, partials);         \
     } while (0)
 #define TRL_GIL_ROW(VR, LG) { if (p.vec) TRL_GIL(VR, LG, true, false); else TRL_GIL(VR, LG, false, false); }
 #define TRL_GIL_ROWS(LG)                          \
@@ -402,27 +408,64 @@ LaunchResult launch_turn(hipStream_t s, const typename P::Args &a, const Plan &p
     }
     if (rowmap && lg == 16) { TRL_GIL_ROWS(16) }
     else if (rowmap) { TRL_GIL_ROWS(32) }
-    else if (p.wave_indep) { if (p.vec) TRL_GIL(0, 16, true, true); else TRL_GIL(0, 16, false, true); }
-    else              { if (p.vec) TRL_GIL(0, 16, true, false); else TRL_GIL(0, 16, false, false); }
+    else if constexpr (NT == kTeam) {
+        if (p.wave_indep) { if (p.vec) TRL_GIL(0, 16, true, true); else TRL_GIL(0, 16, false, true); }
+        else              { if (p.vec) TRL_GIL(0, 16, true, false); else TRL_GIL(0, 16, false, false); }
+    }
 #undef TRL_GIL_ROWS
 #undef TRL_GIL_ROW
 #undef TRL_GIL
     return LaunchResult{0, nb, name};
 }
 
-template <typename TS, typename TG, int V>
-LaunchResult launch_gae_interleaved(hipStream_t s, const GaeArgs &a, const Plan &p, int cus) {
-    return launch_turn<GaeTurn<TS, TG>, V>(s, a, p, cus, a.partials, "gae_scan_interleaved");
+// Outer rows longer than a team's chunk on 1024-thread blocks: T*I <= 1024*V, row mapping only (64 < T <= 256).
+constexpr int kTurnBigThreads = 1024;
+inline bool turn_big_plan(i64 O, i64 T, i64 I, int V, bool ptr_align_ok, Plan &p) {
+    const i64 chunk = (i64)kTurnBigThreads * V;
+    if (I < 2 || T * I > chunk || T * I <= (i64)kTeam * V || T <= 64 || T > 256) return false;
+    // I = 16 stays with the lock-step kernels, whose lanes read one 16-byte vector per tensor there (G = 4 groups of 4): lock-step /
+    // this kernel, us: [4096x100x16] 30.3 / 34.3, [4096x180x16] 45.7 / 59.7, [4096x256x16] 59.7 / 65.6, fp64 [4096x100x16] 56.7 / 60.9.
+    // Everything else measured goes the other way: [4096x100x30] 238 / 60.3, [4096x100x11] 59.5 / 26.9, [4096x120x13] 74.9 / 34.0,
+    // [4096x200x20] 131.7 / 70.5, [4096x100x20] 57.0 / 37.5, [4096x100x14] 44.1 / 31.4, [4096x100x28] 79.9 / 58.4, [4096x150x8]
+    // 33.0 / 27.1, fp64 [4096x100x8] 50.6 / 33.9; ties: [4096x100x24] 57.2 / 56.1, [4096x200x8] 37.0 / 37.4, [4096x250x8] 39.9 / 39.6.
+    if (I == 16) return false;
+    const i64 groups = kTurnBigThreads / (T <= 128 ? 16 : 32);  // (o, i) rows a block's lanes can take
+    i64 R = chunk / (T * I);
+    const i64 q = V / gcd_i64(T * I, V);
+    if (R >= q) R -= R % q;
+    if (R * I > groups) R = groups / I;
+    if (R < 1) return false;
+    if (R > O) R = O;
+    p = Plan{};
+    p.ok = p.interleaved = true;
+    p.rows_per_chunk = (int)R;
+    p.nchunks = (O + R - 1) / R;
+    p.nblocks = p.nchunks;
+    p.vec = ptr_align_ok && (p.nchunks == 1 || (R * T * I) % V == 0);
+    return true;
 }
 
-template <typename TS, typename TG, int V>
-LaunchResult launch_td1_interleaved(hipStream_t s, const TdLambdaArgs &a, const Plan &p, int cus) {
-    return launch_turn<Td1Turn<TS, TG>, V>(s, a, p, cus, nullptr, "td1_scan_interleaved");
-}
-
-template <typename TS, typename TG, int V>
-LaunchResult launch_td_lambda_interleaved(hipStream_t s, const TdLambdaArgs &a, const Plan &p, int cus) {
-    return launch_turn<TdLambdaTurn<TS, TG>, V>(s, a, p, cus, nullptr, "td_lambda_scan_interleaved");
+// dtype dispatch of one policy: the team-sized kernel when whole outer rows fit its chunk, else the 1024-thread one; status 2 =
+// not this kernel's shape.  Instantiated once per estimator in a translation unit of its own (turn_*.hip): these kernels are
+// most of the SCAN family's compile time.
+template <template <class, class> class P, class Args>
+LaunchResult dispatch_turn(hipStream_t s, int vdt, int cdt, const Args &a, bool aligned, double *partials, const char *name) {
+    const int cus = device_cus();
+    auto go = [&](auto tsv, auto tgv, auto vc) -> LaunchResult {
+        typedef decltype(tsv) TS;
+        typedef decltype(tgv) TG;
+        constexpr int V = decltype(vc)::value;
+        Plan p = make_plan(a.O, a.T, a.I, V, aligned, cus);
+        if (p.ok && p.interleaved) return launch_turn<P<TS, TG>, V>(s, a, p, cus, partials, name);
+        if (turn_big_plan(a.O, a.T, a.I, V, aligned, p)) return launch_turn<P<TS, TG>, V, kTurnBigThreads>(s, a, p, cus, partials, name);
+        return LaunchResult{2, 0, nullptr};
+    };
+    // V = 16 bytes of the storage dtype per lane (scan_impl.h dispatch_scan)
+    if (vdt == 0 && cdt == 0) return go(float{}, float{}, std::integral_constant<int, 4>{});
+    if (vdt == 1 && cdt == 1) return go(double{}, double{}, std::integral_constant<int, 2>{});
+    if (vdt == 1 && cdt == 0) return go(double{}, float{}, std::integral_constant<int, 2>{});
+    if (vdt == 0 && cdt == 1) return go(float{}, double{}, std::integral_constant<int, 4>{});
+    return LaunchResult{1, 0, nullptr};
 }
 
 }  // namespace

@@ -635,16 +635,23 @@ Plan make_plan(i64 O, i64 T, i64 I, int V, bool ptr_align_ok, int cus, size_t lb
     return p;
 }
 
+// ops whose feature-dim (I > 1) shapes run on the map-forming transposing kernel (gae_interleaved.h) say kOwnTurnKernel: the
+// generic transposing kernel is then not instantiated for them
+template <class Op, class = void>
+struct OpOwnTurnKernel { static constexpr bool value = false; };
+template <class Op>
+struct OpOwnTurnKernel<Op, std::void_t<decltype(Op::kOwnTurnKernel)>> { static constexpr bool value = Op::kOwnTurnKernel; };
+
 template <class Op>
 LaunchResult launch_scan(hipStream_t s, const typename Op::Args &a, const Plan &p, i64 O, i64 T, i64 I, double *partials,
                          const char *name, void *lb_ws = nullptr) {
     ScanGeom geo{O, T, p.rows_per_chunk, scan_lanes_for(T, Op::V, p.wave_indep), p.nchunks};
     const dim3 grid((unsigned)p.nblocks);
-    if constexpr (Op::kShifted || Op::kReversed) {
+    if constexpr (Op::kShifted || Op::kReversed || OpOwnTurnKernel<Op>::value) {
         if (p.interleaved) return LaunchResult{2, 0, nullptr};  // the shifted layout / the adjoints: I == 1 kernels only
     }
     if (p.interleaved) {
-      if constexpr (!Op::kShifted && !Op::kReversed) {
+      if constexpr (!Op::kShifted && !Op::kReversed && !OpOwnTurnKernel<Op>::value) {
         // bank-conflict padding of the LDS arrays ([8192x128x8] 90 -> 34 us, [8192x64x16] 55 -> 34, [8192x32x8] 11.5 -> 10.1,
         // [8192x100x10] 41.3 -> 40.1; no effect for odd strides: [4096x100x5] 13.0 / 13.1)
         const i64 stride_words = (i64)Op::V * I * (i64)(sizeof(typename Op::TS) / 4);  // between the lanes of one (o, i) row

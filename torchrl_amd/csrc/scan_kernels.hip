@@ -1,6 +1,5 @@
 // SCAN family, forward estimators: instantiations of scan_impl.h behind the launch_*_scan entry points.
 #include "scan_impl.h"
-#include "gae_interleaved.h"
 
 
 size_t scan_lookback_bytes(i64 O, i64 T, i64 I) {
@@ -21,6 +20,11 @@ LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a, 
     const bool al = aligned16(a.reward) && (!a.next_value || aligned16(a.value)) && aligned16(a.next_value) && aligned16(a.done) &&
                     aligned16(a.terminated) && aligned16(a.gamma_t) && aligned16(a.lg_t) && aligned16(a.advantage) &&
                     aligned16(a.value_target);
+    // I > 1: GAE's own transposing kernel (delta / disc formed before the LDS turn; gae_interleaved.h, turn_gae.hip)
+    if (a.I > 1 && a.next_value) {
+        const LaunchResult r = launch_gae_turn(s, vdt, cdt, a, al);
+        if (r.status != 2) return r;
+    }
     auto go = [&](auto op) {
         typedef decltype(op) Op;
         // I == 1, rows of 64 < T <= 128 steps that do not tile a wave, sent through the interleaved kernel as well (an LDS turn
@@ -28,13 +32,9 @@ LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a, 
         // [65536x100] 32.8 / 29.7, [20480x80] 8.0 / 7.5, fp64 [20480x80] 17.9 / 14.7 -- 5 - 10 %, not taken: the un-normalised
         // scan would stop being the very scan of the fused kernel (bit-equal value_target on both routes).
         Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus(), lb_ws ? lb_bytes : 0, a.partials != nullptr);
-        if (!p.ok) return LaunchResult{2, 0, nullptr};
-        if constexpr (!Op::kShifted) {
-            // I > 1: the GAE-specific kernel (delta / disc formed before the LDS turn, gae_interleaved.h)
-            if (p.interleaved) return launch_gae_interleaved<typename Op::TS, typename Op::TG, Op::V>(s, a, p, device_cus());
-        }
+        if (!p.ok || p.interleaved) return LaunchResult{2, 0, nullptr};  // I > 1 here: the shifted layout (I == 1 kernels only)
         return launch_scan<Op>(s, a, p, a.O, a.T, a.I, a.partials,
-                               p.interleaved ? "gae_scan_interleaved" : p.lookback ? "gae_scan_lookback" : p.long_rows ? "gae_scan_long" : "gae_scan_short", lb_ws);
+                               p.lookback ? "gae_scan_lookback" : p.long_rows ? "gae_scan_long" : "gae_scan_short", lb_ws);
     };
     return a.next_value ? dispatch_scan<GaeOp, GaeArgs>(vdt, cdt, go) : dispatch_scan<GaeShiftedOp, GaeArgs>(vdt, cdt, go);
 }
@@ -42,27 +42,32 @@ LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a, 
 LaunchResult launch_td_lambda_scan(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, void *lb_ws, size_t lb_bytes) {
     const bool al = aligned16(a.reward) && aligned16(a.next_value) && aligned16(a.done) && aligned16(a.terminated) &&
                     aligned16(a.gamma_t) && aligned16(a.lmbda_t) && aligned16(a.returns);
+    if (a.I > 1) {  // the map-forming transposing kernel (turn_td_lambda.hip)
+        const LaunchResult r = launch_td_lambda_turn(s, vdt, cdt, a, al);
+        if (r.status != 2) return r;
+    }
     return dispatch_scan<TdLambdaOp, TdLambdaArgs>(vdt, cdt, [&](auto op) {
         typedef decltype(op) Op;
         Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus(), lb_ws ? lb_bytes : 0, false);
-        if (!p.ok) return LaunchResult{2, 0, nullptr};
-        // I > 1: the kernel that forms the maps before the LDS turn (gae_interleaved.h), as GAE
-        if (p.interleaved) return launch_td_lambda_interleaved<typename Op::TS, typename Op::TG, Op::V>(s, a, p, device_cus());
+        if (!p.ok || p.interleaved) return LaunchResult{2, 0, nullptr};
         return launch_scan<Op>(s, a, p, a.O, a.T, a.I, nullptr,
-                               p.interleaved ? "td_lambda_scan_interleaved" : p.lookback ? "td_lambda_scan_lookback" : p.long_rows ? "td_lambda_scan_long" : "td_lambda_scan_short", lb_ws);
+                               p.lookback ? "td_lambda_scan_lookback" : p.long_rows ? "td_lambda_scan_long" : "td_lambda_scan_short", lb_ws);
     });
 }
 
 LaunchResult launch_td1_scan(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, void *lb_ws, size_t lb_bytes) {
     const bool al = aligned16(a.reward) && aligned16(a.next_value) && aligned16(a.done) && aligned16(a.terminated) &&
                     aligned16(a.gamma_t) && aligned16(a.returns);
+    if (a.I > 1) {  // the map-forming transposing kernel (turn_td1.hip)
+        const LaunchResult r = launch_td1_turn(s, vdt, cdt, a, al);
+        if (r.status != 2) return r;
+    }
     return dispatch_scan<Td1Op, TdLambdaArgs>(vdt, cdt, [&](auto op) {
         typedef decltype(op) Op;
         Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus(), lb_ws ? lb_bytes : 0, false);
-        if (!p.ok) return LaunchResult{2, 0, nullptr};
-        if (p.interleaved) return launch_td1_interleaved<typename Op::TS, typename Op::TG, Op::V>(s, a, p, device_cus());
+        if (!p.ok || p.interleaved) return LaunchResult{2, 0, nullptr};
         return launch_scan<Op>(s, a, p, a.O, a.T, a.I, nullptr,
-                               p.interleaved ? "td1_scan_interleaved" : p.lookback ? "td1_scan_lookback" : p.long_rows ? "td1_scan_long" : "td1_scan_short", lb_ws);
+                               p.lookback ? "td1_scan_lookback" : p.long_rows ? "td1_scan_long" : "td1_scan_short", lb_ws);
     });
 }
 
