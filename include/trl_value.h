@@ -60,8 +60,9 @@ enum {
 enum {
     TRL_ALGO_AUTO = 0,
     TRL_ALGO_SEQ = 1, /* one lane per (o,i) row, sequential over t: bit-identical to the reference loop */
-    TRL_ALGO_SCAN = 2, /* wavefront scan of affine maps over time (I == 1): tolerance-level parity,
-                          bit-exact at done boundaries */
+    TRL_ALGO_SCAN = 2, /* wavefront scan of affine maps over time: tolerance-level parity, bit-exact at done boundaries.
+                          I == 1: any T.  I > 1: whole outer rows of at most 256*V elements (V = 4 fp32 / 2 fp64) through an
+                          LDS transpose; GAE, TD(lambda), TD(1) with 64 < T <= 256 and I != 16: up to 1024*V elements */
     TRL_ALGO_FUSED = 3 /* trl_gae_normalize_fwd only: single persistent launch, advantages kept in
                           registers across an in-launch all-gather of the fp64 moments */,
     TRL_ALGO_LOCKSTEP = 4 /* 2 <= I <= 31 feature elements per step (groups of <= 8), any T: a lane owns one time step, the I
