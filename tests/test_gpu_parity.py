@@ -206,7 +206,7 @@ WIDE = [((5, 100, 20), -2), ((3, 100, 30), -2), ((7, 120, 13), -2), ((4, 200, 20
 @pytest.mark.parametrize("shape,time_dim", WIDE, ids=["x".join(map(str, s)) for s, _ in WIDE])
 def test_many_feature_rows_on_wide_blocks(shape, time_dim, dtype):
     """Outer rows of more than a team's chunk (256 * V elements) and at most 1024 * V, 64 < T <= 256 (MAPPO-shaped rollouts with
-    11 - 40 agents): GAE, TD(lambda) and TD(1) on the 1024-thread transposing kernel (gae_interleaved.h, NT = 1024), scalar and
+    11 - 40 agents): GAE, TD(lambda), TD(1) and V-trace on the 1024-thread transposing kernel (gae_interleaved.h, NT = 1024), scalar and
     per-element gamma, compact (expanded) masks, per-block moments; shapes it does not take fall through to LOCKSTEP / SEQ."""
     r, v, nv, done, term, gam, lp, lm = _rand_inputs(shape, dtype, seed=31)
     td = time_dim if time_dim < 0 else time_dim - len(shape)
@@ -229,6 +229,8 @@ def test_many_feature_rows_on_wide_blocks(shape, time_dim, dtype):
             gcall = F._prepare_gae(cu(gamma), 0.9, cu(v), cu(nv), cu(r), dd, tt, time_dim)
             tcall = F._prepare_td_lambda(cu(gamma), 0.9, cu(nv), cu(r), dd, tt, None, time_dim)
             t1call = F._prepare_td1(cu(gamma), cu(nv), cu(r), dd, tt, True, time_dim)
+            ova, ovs = O.vtrace(gamma, lp, lm, v, nv, r, dn, tm, time_dim=time_dim)
+            vcall = F._prepare_vtrace(cu(gamma), cu(lp), cu(lm), cu(v), cu(nv), cu(r), dd, tt, 1.0, 1.0, time_dim)
             for algo in ((F.ALGO_AUTO, SCAN) if wide else (F.ALGO_AUTO,)):
                 adv, vt, st = F._launch_gae(gcall, want_stats=True, algo=algo)
                 if wide:
@@ -246,6 +248,11 @@ def test_many_feature_rows_on_wide_blocks(shape, time_dim, dtype):
                 if wide:
                     assert F.last_kernel() == "td1_scan_interleaved", F.last_kernel()
                 check(ret1, oret1, False)
+                va, vs = F._launch_vtrace(vcall, algo=algo)
+                if wide:
+                    assert F.last_kernel() == "vtrace_scan_interleaved", F.last_kernel()
+                check(va, ova, False)
+                check(vs, ovs, False)
     nadv, _ = F.gae_normalized(0.9, 0.9, cu(v), cu(nv), cu(r), cu(done), cu(term), time_dim=time_dim)
     torch.testing.assert_close(nadv.cpu(), O.normalize(O.gae(0.9, 0.9, v, nv, r, done, term, time_dim=time_dim)[0], 1e-4), rtol=1e-5, atol=1e-5)
 

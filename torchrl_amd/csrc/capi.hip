@@ -184,6 +184,16 @@ static bool td_prefers_transposing(int val_dtype, int coef_dtype, int64_t T, int
     return R * T * I * 100 >= chunk * 75;
 }
 
+// V-trace on the same kernel (policy VtraceTurn), transposing / lock-step us: [4096x100x5] 15.1 / 22.0, [4096x80x5] 12.5 / 17.5,
+// [4096x136x7] 26.8 / 44.3, [8192x60x6] 26.8 / 27.2, [4096x150x8] 43.8 / 49.6, [4096x100x30] 92.6 / 256.7, [4096x100x11] 41.6 / 66.8,
+// fp64 [8192x40x3] 13.7 / 20.2, [4096x100x10] 50.0 / 109.6; with I <= 4 at fp32 the two are within 5 % of each other and the rule
+// above stays ([4096x200x4] 25.4 / 24.4, [8192x100x3] 20.6 / 19.9, [4096x127x3] 15.0 / 12.9).
+static bool vtrace_prefers_transposing(int val_dtype, int64_t T, int64_t I) {
+    if (I < 2) return false;
+    if (T * I > 256 * (val_dtype == TRL_F32 ? 4 : 2)) return scan_turn_big_ok(val_dtype, T, I);
+    return val_dtype == TRL_F64 || I >= 5;
+}
+
 // Outer rows too long for the transposing kernel, 9 <= I <= 31: lock-step groups or the SEQ walk (coalesced only
 // over i, but every (o, i) row is a lane).  Measured fp32 (SEQ / LOCKSTEP us): [64x1000x16] 381 / 20, [1024x300x16]
 // 145 / 62, [4096x300x16] 281 / 218, [1024x100x31] 68 / 65, [8192x100x16] 117 / 146, [16384x64x31] 360 / 817:
@@ -547,7 +557,8 @@ int trl_vtrace_fwd(void *stream, int val_dtype, int coef_dtype, const void *log_
     if (rho_thresh_t || c_thresh_t) algo = TRL_ALGO_SEQ;
     size_t lb_bytes = 0;
     void *lb = lb_region(workspace, workspace_bytes, O, T, I, &lb_bytes);
-    if (algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I)) res = launch_vtrace_lockstep(s, val_dtype, coef_dtype, a);
+    if (algo == TRL_ALGO_AUTO && prefer_lockstep(val_dtype, coef_dtype, T, I) && !(next_state_value && vtrace_prefers_transposing(val_dtype, T, I)))
+        res = launch_vtrace_lockstep(s, val_dtype, coef_dtype, a);
     if (res.status == TRL_ERR_UNSUPPORTED && (algo == TRL_ALGO_AUTO || algo == TRL_ALGO_SCAN))
         res = launch_vtrace_scan(s, val_dtype, coef_dtype, a, lb, lb_bytes);
     if (res.status == TRL_ERR_UNSUPPORTED && algo == TRL_ALGO_SCAN)

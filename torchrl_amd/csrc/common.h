@@ -206,6 +206,7 @@ i64 scan_max_partials(i64 O, i64 T, i64 I);
 LaunchResult launch_gae_turn(hipStream_t s, int vdt, int cdt, const GaeArgs &a, bool aligned);
 LaunchResult launch_td_lambda_turn(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, bool aligned);
 LaunchResult launch_td1_turn(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, bool aligned);
+LaunchResult launch_vtrace_turn(hipStream_t s, int vdt, int cdt, const VtraceArgs &a, bool aligned);
 bool scan_turn_big_ok(int vdt, i64 T, i64 I);  // outer rows of up to 1024 * V elements on the 1024-thread transposing kernel
 i64 seq_max_partials(i64 O, i64 T, i64 I);
 

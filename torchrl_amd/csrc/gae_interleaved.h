@@ -38,8 +38,10 @@ struct GaeTurn {
     typedef TS_ TS;
     typedef TG_ TG;
     typedef typename Promote<TS, TG>::type TC;
+    typedef TS TO;
     typedef GaeArgs Args;
     static constexpr bool kSecondOutput = true;  // value_target = advantage + the state value the lane still holds
+    static constexpr bool kNeedsNext = false, kPrefetch = true;
     template <int V>
     struct Raw {
         TS r[V], v[V], nv[V];
@@ -60,15 +62,26 @@ struct GaeTurn {
         if (lgp) load_n<VEC>(lgp, flat, nvalid, w.lg);
     }
     template <int V>
-    __device__ __forceinline__ void maps(const Raw<V> &w, int e, u8 d, u8 tm, bool, TC &delta, TC &disc) const {
-        const TG ge = gtp ? w.g[e] : gs;
-        const TG ce = lgp ? w.lg[e] : (gtp ? ls * ge : lgs);
-        const TG g_nt = ge * (TG)(tm ? 0 : 1);  // multiply, not select: as the reference
-        disc = (TC)(ce * (TG)(d ? 0 : 1));
-        delta = ((TC)w.r[e] + (TC)g_nt * (TC)w.nv[e]) - (TC)w.v[e];
+    struct Keep { TS v[V]; };  // what the memory-order epilogue still needs of the inputs
+    template <int V>
+    __device__ __forceinline__ void pre(const Raw<V> &w, const u8 (&d)[V], const u8 (&tm)[V], unsigned, TC (&delta)[V], TC (&disc)[V],
+                                        Keep<V> &k) const {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const TG ge = gtp ? w.g[e] : gs;
+            const TG ce = lgp ? w.lg[e] : (gtp ? ls * ge : lgs);
+            const TG g_nt = ge * (TG)(tm[e] ? 0 : 1);  // multiply, not select: as the reference
+            disc[e] = (TC)(ce * (TG)(d[e] ? 0 : 1));
+            delta[e] = ((TC)w.r[e] + (TC)g_nt * (TC)w.nv[e]) - (TC)w.v[e];
+            k.v[e] = w.v[e];
+        }
     }
     template <int V>
-    __device__ __forceinline__ TS kept(const Raw<V> &w, int e) const { return w.v[e]; }
+    __device__ __forceinline__ void post(const Keep<V> &k, int e, TS x, TC, TS, bool, TS &o0, TS &o1) const {
+        o0 = x;
+        o1 = x + k.v[e];  // value_target = advantage + state value
+    }
+    __device__ __forceinline__ TS value_at(i64) const { return (TS)0; }
     static __device__ __forceinline__ TS *out0(const Args &a) { return (TS *)a.advantage; }
     static __device__ __forceinline__ TS *out1(const Args &a) { return (TS *)a.value_target; }
 };
@@ -82,8 +95,9 @@ struct TdLambdaTurn {
     typedef TS_ TS;
     typedef TG_ TG;
     typedef typename Promote<TS, TG>::type TC;
+    typedef TS TO;
     typedef TdLambdaArgs Args;
-    static constexpr bool kSecondOutput = false;
+    static constexpr bool kSecondOutput = false, kNeedsNext = false, kPrefetch = true;
     template <int V>
     struct Raw {
         TS r[V], nv[V];
@@ -103,16 +117,24 @@ struct TdLambdaTurn {
         if (ltp) load_n<VEC>(ltp, flat, nvalid, w.l);
     }
     template <int V>
-    __device__ __forceinline__ void maps(const Raw<V> &w, int e, u8 d, u8 tm, bool row_end, TC &delta, TC &disc) const {
-        const TG gm = gtp ? w.g[e] : gs, lm = ltp ? w.l[e] : ls;
-        const TS nvm = w.nv[e] * (TS)(tm ? 0 : 1), dn = (TS)(d ? 1 : 0), omd = (TS)(d ? 0 : 1);
-        const TG oml = (TG)1 - lm;
-        const TC g1 = row_end ? (TC)nvm * (TC)omd + (TC)(nvm * dn) : (TC)(nvm * dn);  // row end: step(init), init = nvm
-        delta = (TC)w.r[e] + (TC)gm * ((TC)oml * (TC)nvm + (TC)lm * g1);
-        disc = row_end ? (TC)0 : ((TC)gm * (TC)lm) * (TC)omd;
+    struct Keep {};
+    template <int V>
+    __device__ __forceinline__ void pre(const Raw<V> &w, const u8 (&d)[V], const u8 (&tm)[V], unsigned ends, TC (&delta)[V], TC (&disc)[V],
+                                        Keep<V> &) const {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const bool row_end = (ends >> e) & 1u;
+            const TG gm = gtp ? w.g[e] : gs, lm = ltp ? w.l[e] : ls;
+            const TS nvm = w.nv[e] * (TS)(tm[e] ? 0 : 1), dn = (TS)(d[e] ? 1 : 0), omd = (TS)(d[e] ? 0 : 1);
+            const TG oml = (TG)1 - lm;
+            const TC g1 = row_end ? (TC)nvm * (TC)omd + (TC)(nvm * dn) : (TC)(nvm * dn);  // row end: step(init), init = nvm
+            delta[e] = (TC)w.r[e] + (TC)gm * ((TC)oml * (TC)nvm + (TC)lm * g1);
+            disc[e] = row_end ? (TC)0 : ((TC)gm * (TC)lm) * (TC)omd;
+        }
     }
     template <int V>
-    __device__ __forceinline__ TS kept(const Raw<V> &, int) const { return (TS)0; }
+    __device__ __forceinline__ void post(const Keep<V> &, int, TS x, TC, TS, bool, TS &o0, TS &) const { o0 = x; }
+    __device__ __forceinline__ TS value_at(i64) const { return (TS)0; }
     static __device__ __forceinline__ TS *out0(const Args &a) { return (TS *)a.returns; }
     static __device__ __forceinline__ TS *out1(const Args &) { return nullptr; }
 };
@@ -123,8 +145,9 @@ struct Td1Turn {
     typedef TS_ TS;
     typedef TG_ TG;
     typedef typename Promote<TS, TG>::type TC;
+    typedef TS TO;
     typedef TdLambdaArgs Args;
-    static constexpr bool kSecondOutput = false;
+    static constexpr bool kSecondOutput = false, kNeedsNext = false, kPrefetch = true;
     template <int V>
     struct Raw {
         TS r[V], nv[V];
@@ -142,18 +165,94 @@ struct Td1Turn {
         if (gtp) load_n<VEC>(gtp, flat, nvalid, w.g);
     }
     template <int V>
-    __device__ __forceinline__ void maps(const Raw<V> &w, int e, u8 d, u8 tm, bool row_end, TC &delta, TC &disc) const {
-        const TG gnt = (gtp ? w.g[e] : gs) * (TG)(tm ? 0 : 1);
-        const bool b = d && !tm;
-        const TS dnt = (TS)(b ? 1 : 0), omdnt = (TS)(b ? 0 : 1);
-        const TC tail = row_end ? (TC)omdnt * (TC)w.nv[e] + (TC)(dnt * w.nv[e]) : (TC)(dnt * w.nv[e]);  // row end: step(init), init = nv
-        delta = (TC)w.r[e] + (TC)gnt * tail;
-        disc = row_end ? (TC)0 : (TC)gnt * (TC)omdnt;
+    struct Keep {};
+    template <int V>
+    __device__ __forceinline__ void pre(const Raw<V> &w, const u8 (&d)[V], const u8 (&tm)[V], unsigned ends, TC (&delta)[V], TC (&disc)[V],
+                                        Keep<V> &) const {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const bool row_end = (ends >> e) & 1u;
+            const TG gnt = (gtp ? w.g[e] : gs) * (TG)(tm[e] ? 0 : 1);
+            const bool b = d[e] && !tm[e];
+            const TS dnt = (TS)(b ? 1 : 0), omdnt = (TS)(b ? 0 : 1);
+            const TC tail = row_end ? (TC)omdnt * (TC)w.nv[e] + (TC)(dnt * w.nv[e]) : (TC)(dnt * w.nv[e]);  // row end: step(init), init = nv
+            delta[e] = (TC)w.r[e] + (TC)gnt * tail;
+            disc[e] = row_end ? (TC)0 : (TC)gnt * (TC)omdnt;
+        }
     }
     template <int V>
-    __device__ __forceinline__ TS kept(const Raw<V> &, int) const { return (TS)0; }
+    __device__ __forceinline__ void post(const Keep<V> &, int, TS x, TC, TS, bool, TS &o0, TS &) const { o0 = x; }
+    __device__ __forceinline__ TS value_at(i64) const { return (TS)0; }
     static __device__ __forceinline__ TS *out0(const Args &a) { return (TS *)a.returns; }
     static __device__ __forceinline__ TS *out1(const Args &) { return nullptr; }
+};
+
+// V-trace (scan_core.h VtraceOp: the same sub-expressions).  x is the scanned correction vs - v; the outputs need the NEXT step's
+// vs = x + v: in memory order that is the element I positions further -- its x from the LDS array the row phase just filled, its
+// state value re-read from global memory (a line this block loaded moments ago).  The shift ignores done (functional.py:1343-1345):
+// only the step that ends a row takes next_value instead.
+template <typename TS_, typename TG_>
+struct VtraceTurn {
+    typedef TS_ TS;
+    typedef TG_ TG;
+    typedef typename Promote<TS, TG>::type TC;
+    typedef TC TO;  // as VtraceOp: outputs in the promoted dtype
+    typedef VtraceArgs Args;
+    static constexpr bool kSecondOutput = true, kNeedsNext = true;
+    static constexpr bool kPrefetch = false;  // six input arrays: the next chunk's would not fit the register file beside this one's
+    template <int V>
+    struct Raw {
+        TS lp[V], lmu[V], v[V], nv[V], r[V];
+        TG g[V];
+    };
+    template <int V>
+    struct Keep {
+        TS v[V], nv[V], r[V], crho[V];
+        TG td[V];
+    };
+    const TS *__restrict__ lpp, *__restrict__ lmp, *__restrict__ vp, *__restrict__ nvp, *__restrict__ rp;
+    const TG *__restrict__ gtp;
+    TG gs;
+    TS rho_hi, c_hi;
+    __device__ __forceinline__ explicit VtraceTurn(const Args &a)
+        : lpp((const TS *)a.log_pi), lmp((const TS *)a.log_mu), vp((const TS *)a.value), nvp((const TS *)a.next_value),
+          rp((const TS *)a.reward), gtp((const TG *)a.gamma_t), gs((TG)a.gamma), rho_hi((TS)a.rho_thresh), c_hi((TS)a.c_thresh) {}
+    template <bool VEC, int V>
+    __device__ __forceinline__ void load(i64 flat, int nvalid, Raw<V> &w) const {
+        load_n<VEC>(lpp, flat, nvalid, w.lp);
+        load_n<VEC>(lmp, flat, nvalid, w.lmu);
+        load_n<VEC>(vp, flat, nvalid, w.v);
+        load_n<VEC>(nvp, flat, nvalid, w.nv);
+        load_n<VEC>(rp, flat, nvalid, w.r);
+        if (gtp) load_n<VEC>(gtp, flat, nvalid, w.g);
+    }
+    template <int V>
+    __device__ __forceinline__ void pre(const Raw<V> &w, const u8 (&d)[V], const u8 (&tm)[V], unsigned, TC (&delta)[V], TC (&disc)[V],
+                                        Keep<V> &k) const {
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const TG ge = gtp ? w.g[e] : gs;
+            const TG dd = ge * (TG)(d[e] ? 0 : 1);
+            k.td[e] = ge * (TG)(tm[e] ? 0 : 1);
+            const TS rho = exp_t(w.lp[e] - w.lmu[e]);
+            k.crho[e] = clamp_max_nan(rho, rho_hi);
+            const TS cc = clamp_max_nan(rho, c_hi);
+            k.v[e] = w.v[e];
+            k.nv[e] = w.nv[e];
+            k.r[e] = w.r[e];
+            delta[e] = (TC)k.crho[e] * (((TC)w.r[e] + (TC)k.td[e] * (TC)w.nv[e]) - (TC)w.v[e]);
+            disc[e] = (TC)dd * (TC)cc;
+        }
+    }
+    template <int V>
+    __device__ __forceinline__ void post(const Keep<V> &k, int e, TO x, TC x_next, TS v_next, bool row_end, TO &adv, TO &vs) const {
+        const TC nxt = row_end ? (TC)k.nv[e] : x_next + (TC)v_next;
+        adv = (TC)k.crho[e] * (((TC)k.r[e] + (TC)k.td[e] * nxt) - (TC)k.v[e]);
+        vs = x + (TC)k.v[e];
+    }
+    __device__ __forceinline__ TS value_at(i64 idx) const { return vp[idx]; }
+    static __device__ __forceinline__ TO *out0(const Args &a) { return (TO *)a.advantage; }
+    static __device__ __forceinline__ TO *out1(const Args &a) { return (TO *)a.vs; }
 };
 
 // 4 blocks of 4 waves per CU and a grid of exactly that many blocks: with the next chunk's loads in flight a lane holds two
@@ -184,6 +283,7 @@ template <class P, int V, int VR, int LG, bool VEC, bool WAVE_INDEP, bool PAD, i
 __global__ __launch_bounds__(NT, kGilBlocksPerCu) void gae_interleaved_kernel(typename P::Args args, ScanGeom geo, int I, double *partials) {
     typedef typename P::TS TS;
     typedef typename P::TC TC;
+    typedef typename P::TO TO;  // what the row phase leaves in LDS and the epilogue writes (V-trace: the promoted dtype)
     typedef GaePreparedOp<TS, TC, V> Op;
     static_assert(NT == kTeam || VR > 0, "blocks wider than a team exist for the row mapping only");
     constexpr int CH = NT * V;
@@ -191,7 +291,7 @@ __global__ __launch_bounds__(NT, kGilBlocksPerCu) void gae_interleaved_kernel(ty
     auto pad = [&](int p) { return PAD ? p + ((p >> 7) << 2) : p; };  // scan_impl.h: bank-conflict padding, 16-byte accesses kept
     __shared__ __align__(16) TC ld_d[CHP];
     __shared__ __align__(16) TC ld_c[CHP];
-    __shared__ __align__(16) TS ld_o[CHP];
+    __shared__ __align__(16) TO ld_o[CHP];
     __shared__ TeamShared<Op> sh;
     __shared__ double red[2 * (NT / kWave)];
     const int lane_off = (int)threadIdx.x * V;
@@ -264,20 +364,21 @@ __global__ __launch_bounds__(NT, kGilBlocksPerCu) void gae_interleaved_kernel(ty
     double s = 0.0, ss = 0.0;
     const i64 niter = (geo.nchunks + gridDim.x - 1) / gridDim.x;
     Raw cur, nxt;
-    load_raw(0, cur);
+    if constexpr (P::kPrefetch) load_raw(0, cur);
     for (i64 it = 0; it < niter; ++it) {
-        if (it + 1 < niter) load_raw(it + 1, nxt);  // the next chunk's loads fly while this one goes through LDS
+        if constexpr (P::kPrefetch) {
+            if (it + 1 < niter) load_raw(it + 1, nxt);  // the next chunk's loads fly while this one goes through LDS
+        } else {
+            load_raw(it, cur);
+        }
         i64 row0, start;
         int count;
         geom_of(it, row0, start, count);
         const int nvalid = clamp_nvalid(count, lane_off, V);
         const i64 flat = start + lane_off;
-        TS v[V];  // what the second output adds to the first (GAE: the state value)
-#pragma unroll
-        for (int e = 0; e < V; ++e) v[e] = pol.kept(cur.val, e);
+        typename P::template Keep<V> keep;  // what the memory-order epilogue still needs of the inputs (GAE: the state value)
         TC delta[V], disc[V];
-#pragma unroll
-        for (int e = 0; e < V; ++e) pol.maps(cur.val, e, cur.d[e], cur.tm[e], (ends >> e) & 1u, delta[e], disc[e]);
+        pol.pre(cur.val, cur.d, cur.tm, ends, delta, disc, keep);
         {
             TC *dd = (TC *)__builtin_assume_aligned(ld_d + pad(lane_off), 16);
             TC *dc = (TC *)__builtin_assume_aligned(ld_c + pad(lane_off), 16);
@@ -320,7 +421,7 @@ __global__ __launch_bounds__(NT, kGilBlocksPerCu) void gae_interleaved_kernel(ty
             for (int e = VR - 1; e >= 0; --e) {
                 x = dl[e] + x * dc[e];
                 if (row_ok && pr[e] >= 0) {
-                    const TS a = (TS)x;
+                    const TO a = (TO)x;
                     ld_o[pr[e]] = a;
                     s += (double)a;
                     ss += (double)a * (double)a;
@@ -340,7 +441,7 @@ __global__ __launch_bounds__(NT, kGilBlocksPerCu) void gae_interleaved_kernel(ty
 #pragma unroll
                                        for (int e = 0; e < V; ++e) {
                                            if (e < nvalid) {
-                                               const TS a = (TS)xs[e];
+                                               const TO a = (TO)xs[e];
                                                ld_o[pe[e]] = a;
                                                s += (double)a;
                                                ss += (double)a * (double)a;
@@ -351,17 +452,26 @@ __global__ __launch_bounds__(NT, kGilBlocksPerCu) void gae_interleaved_kernel(ty
         __syncthreads();
         // ---- memory order again: (GAE) value_target = advantage + v, coalesced stores --------------------------------------
         {
-            TS adv[V], vt[V];
-            const TS *src = (const TS *)__builtin_assume_aligned(ld_o + pad(lane_off), 16);
+            TO o0[V], o1[V];
+            const TO *src = (const TO *)__builtin_assume_aligned(ld_o + pad(lane_off), 16);
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                adv[e] = src[e];
-                vt[e] = adv[e] + v[e];
+                const bool row_end = (ends >> e) & 1u;
+                TC x_next = (TC)0;
+                TS v_next = (TS)0;
+                if constexpr (P::kNeedsNext) {  // the same (o, i) row's next step sits I elements further in memory order
+                    if (e < nvalid && !row_end) {
+                        x_next = (TC)ld_o[pad(lane_off + e + I)];
+                        v_next = pol.value_at(flat + e + I);
+                    }
+                }
+                o1[e] = (TO)0;
+                pol.post(keep, e, src[e], x_next, v_next, row_end, o0[e], o1[e]);
             }
-            store_n<VEC>(P::out0(args), flat, nvalid, adv);
-            if constexpr (P::kSecondOutput) store_n<VEC>(P::out1(args), flat, nvalid, vt);
+            store_n<VEC>(P::out0(args), flat, nvalid, o0);
+            if constexpr (P::kSecondOutput) store_n<VEC>(P::out1(args), flat, nvalid, o1);
         }
-        cur = nxt;
+        if constexpr (P::kPrefetch) cur = nxt;
     }
     if (partials) {
         block_sum2<NT>(s, ss, red);

@@ -538,6 +538,7 @@ struct VtraceOp {
     static constexpr bool kNeedsNext = true;
     static constexpr bool kShifted = false;
     static constexpr bool kReversed = false;
+    static constexpr bool kOwnTurnKernel = true;  // I > 1: gae_interleaved.h
     static constexpr bool kCustomEmit = false;
     struct Raw {
         TS lp[V], lmu[V], v[V], nv[V], r[V];

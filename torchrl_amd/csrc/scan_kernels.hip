@@ -76,6 +76,10 @@ LaunchResult launch_vtrace_scan(hipStream_t s, int vdt, int cdt, const VtraceArg
     const bool al = aligned16(a.log_pi) && aligned16(a.log_mu) && (!a.next_value || aligned16(a.value)) && aligned16(a.next_value) &&
                     aligned16(a.reward) && aligned16(a.done) && aligned16(a.terminated) && aligned16(a.gamma_t) &&
                     aligned16(a.advantage) && aligned16(a.vs);
+    if (a.I > 1 && a.next_value) {  // the map-forming transposing kernel (turn_vtrace.hip)
+        const LaunchResult r = launch_vtrace_turn(s, vdt, cdt, a, al);
+        if (r.status != 2) return r;
+    }
     auto go = [&](auto op) {
         typedef decltype(op) Op;
         Plan p = make_plan(a.O, a.T, a.I, Op::V, al, device_cus(), lb_ws ? lb_bytes : 0, false);
