@@ -10,7 +10,8 @@
 // Same arithmetic as every other family: the lane replays its steps with delta + x*disc from its carry-in.
 // Round 3: the estimator-specific parts are policies (GaeTurn, TdLambdaTurn, Td1Turn): TD(lambda) / TD(1) returns with rolling
 // gamma take the same route -- C3-shaped TD(lambda) 11.1 -> 8.8 us, [4096x136x7] 18.3 -> 13.3, fp64 C3 17.6 -> 12.7 against the
-// generic transposing kernel of scan_impl.h, which keeps V-trace (its outputs need the next step's x and value).
+// generic transposing kernel that scan_impl.h held until then; V-trace followed (VtraceTurn: its outputs need the next step's x and
+// value, read in memory order I elements further) and that kernel is gone.
 #pragma once
 #include "scan_impl.h"
 

@@ -312,7 +312,6 @@ struct GaeOp {
     static constexpr bool kNeedsNext = false;
     static constexpr bool kShifted = false;  // see Shifted<> below
     static constexpr bool kReversed = false;    // see the adjoint ops (bwd_ops.h)
-    static constexpr bool kOwnTurnKernel = true;  // I > 1: gae_interleaved.h
     static constexpr bool kCustomEmit = false;
     // look-back kernel (scan_impl.h): two 1024-thread blocks per CU (8 waves per SIMD) when the op fits 64 VGPRs (fp32: 70
     // without the hint)
@@ -401,7 +400,6 @@ struct TdLambdaOp {
     static constexpr bool kNeedsNext = false;
     static constexpr bool kShifted = false;
     static constexpr bool kReversed = false;
-    static constexpr bool kOwnTurnKernel = true;  // I > 1: gae_interleaved.h
     static constexpr bool kCustomEmit = false;
     struct Raw {
         TS r[V], nv[V];
@@ -474,7 +472,6 @@ struct Td1Op {
     static constexpr bool kNeedsNext = false;
     static constexpr bool kShifted = false;
     static constexpr bool kReversed = false;
-    static constexpr bool kOwnTurnKernel = true;  // I > 1: gae_interleaved.h
     static constexpr bool kCustomEmit = false;
     struct Raw {
         TS r[V], nv[V];
@@ -538,7 +535,6 @@ struct VtraceOp {
     static constexpr bool kNeedsNext = true;
     static constexpr bool kShifted = false;
     static constexpr bool kReversed = false;
-    static constexpr bool kOwnTurnKernel = true;  // I > 1: gae_interleaved.h
     static constexpr bool kCustomEmit = false;
     struct Raw {
         TS lp[V], lmu[V], v[V], nv[V], r[V];

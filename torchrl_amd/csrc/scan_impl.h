@@ -128,161 +128,10 @@ __global__ __launch_bounds__(kShortThreads) void scan_short_kernel(typename Op::
 }
 
 
-// ---- SHORT rows with feature dims (I > 1, T*I <= chunk) -------------------------------------------
-// Element (o, t, i) sits at (o*T + t)*I + i: the I scans of one outer row are interleaved in
-// memory.  A team takes a chunk of RO whole outer rows (one contiguous byte range per tensor),
-// loads it with the same coalesced 16-byte loads as the I == 1 kernels, and transposes it through
-// LDS so that every lane ends up holding V consecutive time steps of ONE (o, i) row: the chunk
-// then looks exactly like RO*I time-contiguous rows of length T and goes through the same
-// scan_chunk.  Outputs take the inverse route (LDS scatter, coalesced 16-byte stores), so HBM
-// traffic stays at the algorithmic bytes.
-template <class Op, bool VEC, bool WAVE_INDEP, bool PAD>
-__global__ __launch_bounds__(kTeam, 4) void scan_interleaved_kernel(typename Op::Args args, ScanGeom geo, int I, double *partials) {
-    typedef typename Op::TC TC;
-    typedef typename Op::TS TS;
-    typedef typename Op::TO TO;
-    constexpr int V = Op::V;
-    constexpr int CH = kTeam * V;
-    // The gather / scatter by (o, i) row walks the LDS arrays with a stride of V*I elements between lanes.  When that is a
-    // multiple of 8 words a row's lanes fold onto 4, 2 or 1 of the 32 banks ([8192x128x8] 90 us): the arrays then carry 4
-    // pad elements per 128 (index p -> p + 4 * (p / 128)), which spreads the lanes again and keeps the staging's 16-byte
-    // LDS accesses aligned (34 us; one pad element per 32 was conflict-free but made the staging scalar: 40 us).
-    constexpr int CHP = CH + CH / 32;
-    constexpr bool padded = PAD;  // chosen by the launcher (launch_scan)
-    auto pad = [&](int p) { return padded ? p + ((p >> 7) << 2) : p; };
-    __shared__ __align__(16) unsigned char lds_in[sizeof(typename Op::Raw) * kTeam / 32 * 33];
-    __shared__ __align__(16) TO lds_out[Op::kNumOut][CHP];
-    __shared__ TeamShared<Op> sh;
-    __shared__ double red[2 * kWaves];
-    const int lane_off = (int)threadIdx.x * V;
-    const unsigned T = (unsigned)geo.T;
-    const i64 row_elems = geo.T * I;  // elements of one outer row
-
-    // virtual (row-major per (o,i)) position of this lane's first element inside a chunk, and the
-    // physical in-chunk offset of each of its V elements
-    int pe[V], pm[V];  // pm: offset of the step's mask byte when the masks are shared by the I feature elements
-    {
-        unsigned rv = (unsigned)lane_off / T, t = (unsigned)lane_off % T;
-        unsigned ol = rv / (unsigned)I, i = rv % (unsigned)I;
-#pragma unroll
-        for (int e = 0; e < V; ++e) {
-            pe[e] = pad((int)((ol * T + t) * (unsigned)I + i));
-            pm[e] = pad((int)(ol * T + t));
-            if (++t == T) { t = 0; if (++i == (unsigned)I) { i = 0; ++ol; } }
-        }
-    }
-    const unsigned t0 = (unsigned)lane_off % T;
-    const bool bcast = args.mask_bcast != 0;
-    const bool mvec = VEC && ((geo.rows_per_chunk * geo.T) % 4 == 0);  // mask chunk starts stay dword-aligned
-
-    auto geom_of = [&](i64 c, i64 &start, int &count) {
-        const i64 row0 = c * geo.rows_per_chunk;
-        i64 nrows = c < geo.nchunks ? geo.O - row0 : 0;
-        if (nrows > geo.rows_per_chunk) nrows = geo.rows_per_chunk;
-        if (nrows < 0) nrows = 0;
-        start = row0 * row_elems;
-        count = (int)(nrows * row_elems);
-    };
-
-    double s = 0.0, ss = 0.0;
-    i64 start;
-    int count;
-    // No register prefetch here: the kernel is occupancy-bound (VGPRs), and with up to 8 teams per
-    // CU in flight the other teams' loads cover this team's latency.
-    const i64 niter = (geo.nchunks + gridDim.x - 1) / gridDim.x;
-    for (i64 it = 0; it < niter; ++it) {
-        const i64 c = it * gridDim.x + blockIdx.x;
-        geom_of(c, start, count);
-        const int nvalid = clamp_nvalid(count, lane_off, V);
-        typename Op::Raw cur;
-        Op::for_each_input(args, cur, [&](auto *base, auto &arr) {
-            typedef typename std::remove_reference<decltype(arr[0])>::type E;
-            if (!base) return;
-            if (sizeof(E) == 1 && bcast) {  // (count / I) mask bytes, one per step of the chunk's outer rows
-                const i64 mstart = c * geo.rows_per_chunk * geo.T;  // = start / I without the division
-                const int mvalid = clamp_nvalid((int)(count == (int)(geo.rows_per_chunk * row_elems) ? geo.rows_per_chunk * geo.T : count / I), lane_off, V);
-                if (mvec) load_n<true>(base, mstart + lane_off, mvalid, arr);
-                else load_n<false>(base, mstart + lane_off, mvalid, arr);
-            } else {
-                load_n<VEC>(base, start + lane_off, nvalid, arr);
-            }
-        });
-        // stage the chunk in LDS in memory order, then gather this lane's (o,i)-row elements
-        {
-            size_t off = 0;
-            Op::for_each_input(args, cur, [&](auto *base, auto &arr) {
-                typedef typename std::remove_reference<decltype(arr[0])>::type E;
-                if (base) {
-                    if (padded) {  // a lane's V elements share a group: contiguous and still aligned
-                        E *dst = (E *)__builtin_assume_aligned((E *)(lds_in + off) + pad(lane_off), V * sizeof(E) <= 16 ? V * sizeof(E) : 16);
-#pragma unroll
-                        for (int e = 0; e < V; ++e) dst[e] = arr[e];
-                    } else {
-                        E *dst = (E *)(lds_in + off) + lane_off;
-#pragma unroll
-                        for (int e = 0; e < V; ++e) dst[e] = arr[e];
-                    }
-                }
-                off += sizeof(E) * CHP;
-            });
-        }
-        __syncthreads();
-        typename Op::Raw vraw;
-        {
-            size_t off = 0;
-            Op::for_each_input(args, vraw, [&](auto *base, auto &arr) {
-                typedef typename std::remove_reference<decltype(arr[0])>::type E;
-                if (base) {
-                    const E *src = (const E *)(lds_in + off);
-#pragma unroll
-                    for (int e = 0; e < V; ++e) arr[e] = e < nvalid ? src[(sizeof(E) == 1 && bcast) ? pm[e] : pe[e]] : (E)0;
-                }
-                off += sizeof(E) * CHP;
-            });
-        }
-        Op op;
-        op.prepare(args, vraw);
-        TC Xc = (TC)0;
-        TS Xv = (TS)0;
-        scan_chunk<Op, WAVE_INDEP>(op, sh, (int)(it & 1), nvalid, t0, T, geo.scan_lanes, Xc, Xv,
-                                   [&](const TC(&xs)[V], const bool(&row_end)[V], TC x_in, TS v_next) {
-                                       TO o0[V], o1[V];
-                                       op.outputs(nvalid, xs, row_end, x_in, v_next, o0, o1, s, ss);
-#pragma unroll
-                                       for (int e = 0; e < V; ++e) {
-                                           if (e < nvalid) {
-                                               lds_out[0][pe[e]] = o0[e];
-                                               if (Op::kNumOut > 1) lds_out[Op::kNumOut - 1][pe[e]] = o1[e];
-                                           }
-                                       }
-                                   });
-        __syncthreads();
-        {
-            TO o0[V], o1[V];
-            if (padded) {
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    o0[e] = lds_out[0][pad(lane_off) + e];
-                    o1[e] = lds_out[Op::kNumOut - 1][pad(lane_off) + e];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    o0[e] = lds_out[0][lane_off + e];
-                    o1[e] = lds_out[Op::kNumOut - 1][lane_off + e];
-                }
-            }
-            store_outputs<Op, VEC>(args, start + lane_off, nvalid, o0, o1);
-        }
-    }
-    if (partials) {
-        block_sum2<kTeam>(s, ss, red);
-        if (threadIdx.x == 0) {
-            partials[2 * (i64)blockIdx.x] = s;
-            partials[2 * (i64)blockIdx.x + 1] = ss;
-        }
-    }
-}
+// ---- SHORT rows with feature dims (I > 1, T*I <= chunk): gae_interleaved.h ---------------------------------
+// (the generic transposing kernel that lived here -- every input array staged through LDS, the Op's own scan_chunk on the
+// gathered rows -- served TD(lambda) / TD(1) / V-trace until round 3; all four estimators now run on the map-forming kernel of
+// gae_interleaved.h, which moves 2 arrays instead of 5 - 7 across LDS.  make_plan below still lays the chunks out for it.)
 
 // ---- LONG rows: one team per block walks (row, chunk) pairs from each row's end -----------------
 // DUAL: interior chunks (no row end inside) take the scan without the hard-reset machinery.  Chosen by the launcher for rows
@@ -635,37 +484,15 @@ Plan make_plan(i64 O, i64 T, i64 I, int V, bool ptr_align_ok, int cus, size_t lb
     return p;
 }
 
-// ops whose feature-dim (I > 1) shapes run on the map-forming transposing kernel (gae_interleaved.h) say kOwnTurnKernel: the
-// generic transposing kernel is then not instantiated for them
-template <class Op, class = void>
-struct OpOwnTurnKernel { static constexpr bool value = false; };
-template <class Op>
-struct OpOwnTurnKernel<Op, std::void_t<decltype(Op::kOwnTurnKernel)>> { static constexpr bool value = Op::kOwnTurnKernel; };
-
 template <class Op>
 LaunchResult launch_scan(hipStream_t s, const typename Op::Args &a, const Plan &p, i64 O, i64 T, i64 I, double *partials,
                          const char *name, void *lb_ws = nullptr) {
     ScanGeom geo{O, T, p.rows_per_chunk, scan_lanes_for(T, Op::V, p.wave_indep), p.nchunks};
     const dim3 grid((unsigned)p.nblocks);
-    if constexpr (Op::kShifted || Op::kReversed || OpOwnTurnKernel<Op>::value) {
-        if (p.interleaved) return LaunchResult{2, 0, nullptr};  // the shifted layout / the adjoints: I == 1 kernels only
-    }
-    if (p.interleaved) {
-      if constexpr (!Op::kShifted && !Op::kReversed && !OpOwnTurnKernel<Op>::value) {
-        // bank-conflict padding of the LDS arrays ([8192x128x8] 90 -> 34 us, [8192x64x16] 55 -> 34, [8192x32x8] 11.5 -> 10.1,
-        // [8192x100x10] 41.3 -> 40.1; no effect for odd strides: [4096x100x5] 13.0 / 13.1)
-        const i64 stride_words = (i64)Op::V * I * (i64)(sizeof(typename Op::TS) / 4);  // between the lanes of one (o, i) row
-        const bool pad_lds = stride_words % 8 == 0;                                     // a row folds onto <= 4 of the 32 banks
-#define TRL_LAUNCH(VEC, WI)                                                                                                   \
-    do {                                                                                                                      \
-        if (pad_lds) hipLaunchKernelGGL((scan_interleaved_kernel<Op, VEC, WI, true>), grid, dim3(kTeam), 0, s, a, geo, (int)I, partials); \
-        else hipLaunchKernelGGL((scan_interleaved_kernel<Op, VEC, WI, false>), grid, dim3(kTeam), 0, s, a, geo, (int)I, partials);          \
-    } while (0)
-        if (p.wave_indep) { if (p.vec) TRL_LAUNCH(true, true); else TRL_LAUNCH(false, true); }
-        else              { if (p.vec) TRL_LAUNCH(true, false); else TRL_LAUNCH(false, false); }
-#undef TRL_LAUNCH
-      }
-    } else if (p.lookback) {
+    // I > 1 (whole outer rows inside one chunk): the forward estimators run on the kernels of gae_interleaved.h (turn_*.hip); the
+    // shifted layout and the adjoints have I == 1 kernels only
+    if (p.interleaved) return LaunchResult{2, 0, nullptr};
+    if (p.lookback) {
         LbHeader *hdr = (LbHeader *)lb_ws;
         LbRecord *rec = (LbRecord *)((char *)lb_ws + sizeof(LbHeader));
         if (hipMemsetAsync(lb_ws, 0, sizeof(LbHeader) + (size_t)p.nblocks * sizeof(LbRecord), s) != hipSuccess)
