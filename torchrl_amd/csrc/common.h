@@ -202,7 +202,7 @@ LaunchResult launch_gae_lockstep(hipStream_t s, int vdt, int cdt, const GaeArgs 
 LaunchResult launch_td_lambda_lockstep(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a);
 LaunchResult launch_vtrace_lockstep(hipStream_t s, int vdt, int cdt, const VtraceArgs &a);
 i64 scan_max_partials(i64 O, i64 T, i64 I);
-// feature dims after time on the map-forming transposing kernels (gae_interleaved.h; turn_*.hip); status 2: not their shape
+// feature dims after time on the map-forming transposing kernels (gae_interleaved.h; instantiated in scan_kernels.hip); status 2: not their shape
 LaunchResult launch_gae_turn(hipStream_t s, int vdt, int cdt, const GaeArgs &a, bool aligned);
 LaunchResult launch_td_lambda_turn(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, bool aligned);
 LaunchResult launch_td1_turn(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, bool aligned);

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NT, kGilBlocksPerCu) void gae_interleaved_kernel(ty
     static_assert(NT == kTeam || VR > 0, "blocks wider than a team exist for the row mapping only");
     constexpr int CH = NT * V;
     constexpr int CHP = CH + CH / 32;
-    auto pad = [&](int p) { return PAD ? p + ((p >> 7) << 2) : p; };  // scan_impl.h: bank-conflict padding, 16-byte accesses kept
+    auto pad = [&](int p) __attribute__((always_inline)) { return PAD ? p + ((p >> 7) << 2) : p; };  // scan_impl.h: bank-conflict padding, 16-byte accesses kept
     __shared__ __align__(16) TC ld_d[CHP];
     __shared__ __align__(16) TC ld_c[CHP];
     __shared__ __align__(16) TO ld_o[CHP];
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(NT, kGilBlocksPerCu) void gae_interleaved_kernel(ty
         typename P::template Raw<V> val;
         u8 d[V], tm[V];
     };
-    auto geom_of = [&](i64 it, i64 &row0, i64 &start, int &count) {
+    auto geom_of = [&](i64 it, i64 &row0, i64 &start, int &count) __attribute__((always_inline)) {
         const i64 c = it * gridDim.x + blockIdx.x;
         row0 = c * geo.rows_per_chunk;
         i64 nrows = c < geo.nchunks ? geo.O - row0 : 0;
@@ -341,7 +341,8 @@ __global__ __launch_bounds__(NT, kGilBlocksPerCu) void gae_interleaved_kernel(ty
         start = row0 * row_elems;
         count = (int)(nrows * row_elems);
     };
-    auto load_raw = [&](i64 it, Raw &w) {
+    // (always_inline: left to the inliner, the two call sites compiled differently from one translation unit to another -- C3 8.7 vs 9.9 us)
+    auto load_raw = [&](i64 it, Raw &w) __attribute__((always_inline)) {
         i64 row0, start;
         int count;
         geom_of(it, row0, start, count);
@@ -557,8 +558,7 @@ inline bool turn_big_plan(i64 O, i64 T, i64 I, int V, bool ptr_align_ok, Plan &p
 }
 
 // dtype dispatch of one policy: the team-sized kernel when whole outer rows fit its chunk, else the 1024-thread one; status 2 =
-// not this kernel's shape.  Instantiated once per estimator in a translation unit of its own (turn_*.hip): these kernels are
-// most of the SCAN family's compile time.
+// not this kernel's shape.  Instantiated once per estimator at the end of scan_kernels.hip.
 template <template <class, class> class P, class Args>
 LaunchResult dispatch_turn(hipStream_t s, int vdt, int cdt, const Args &a, bool aligned, double *partials, const char *name) {
     const int cus = device_cus();

@@ -489,7 +489,7 @@ LaunchResult launch_scan(hipStream_t s, const typename Op::Args &a, const Plan &
                          const char *name, void *lb_ws = nullptr) {
     ScanGeom geo{O, T, p.rows_per_chunk, scan_lanes_for(T, Op::V, p.wave_indep), p.nchunks};
     const dim3 grid((unsigned)p.nblocks);
-    // I > 1 (whole outer rows inside one chunk): the forward estimators run on the kernels of gae_interleaved.h (turn_*.hip); the
+    // I > 1 (whole outer rows inside one chunk): the forward estimators run on the kernels of gae_interleaved.h; the
     // shifted layout and the adjoints have I == 1 kernels only
     if (p.interleaved) return LaunchResult{2, 0, nullptr};
     if (p.lookback) {

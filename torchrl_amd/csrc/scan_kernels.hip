@@ -1,5 +1,6 @@
 // SCAN family, forward estimators: instantiations of scan_impl.h behind the launch_*_scan entry points.
 #include "scan_impl.h"
+#include "gae_interleaved.h"
 
 
 size_t scan_lookback_bytes(i64 O, i64 T, i64 I) {
@@ -20,7 +21,7 @@ LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a, 
     const bool al = aligned16(a.reward) && (!a.next_value || aligned16(a.value)) && aligned16(a.next_value) && aligned16(a.done) &&
                     aligned16(a.terminated) && aligned16(a.gamma_t) && aligned16(a.lg_t) && aligned16(a.advantage) &&
                     aligned16(a.value_target);
-    // I > 1: GAE's own transposing kernel (delta / disc formed before the LDS turn; gae_interleaved.h, turn_gae.hip)
+    // I > 1: GAE's own transposing kernel (delta / disc formed before the LDS turn; gae_interleaved.h)
     if (a.I > 1 && a.next_value) {
         const LaunchResult r = launch_gae_turn(s, vdt, cdt, a, al);
         if (r.status != 2) return r;
@@ -42,7 +43,7 @@ LaunchResult launch_gae_scan(hipStream_t s, int vdt, int cdt, const GaeArgs &a, 
 LaunchResult launch_td_lambda_scan(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, void *lb_ws, size_t lb_bytes) {
     const bool al = aligned16(a.reward) && aligned16(a.next_value) && aligned16(a.done) && aligned16(a.terminated) &&
                     aligned16(a.gamma_t) && aligned16(a.lmbda_t) && aligned16(a.returns);
-    if (a.I > 1) {  // the map-forming transposing kernel (turn_td_lambda.hip)
+    if (a.I > 1) {  // the map-forming transposing kernel (end of this file)
         const LaunchResult r = launch_td_lambda_turn(s, vdt, cdt, a, al);
         if (r.status != 2) return r;
     }
@@ -58,7 +59,7 @@ LaunchResult launch_td_lambda_scan(hipStream_t s, int vdt, int cdt, const TdLamb
 LaunchResult launch_td1_scan(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, void *lb_ws, size_t lb_bytes) {
     const bool al = aligned16(a.reward) && aligned16(a.next_value) && aligned16(a.done) && aligned16(a.terminated) &&
                     aligned16(a.gamma_t) && aligned16(a.returns);
-    if (a.I > 1) {  // the map-forming transposing kernel (turn_td1.hip)
+    if (a.I > 1) {  // the map-forming transposing kernel (end of this file)
         const LaunchResult r = launch_td1_turn(s, vdt, cdt, a, al);
         if (r.status != 2) return r;
     }
@@ -76,7 +77,7 @@ LaunchResult launch_vtrace_scan(hipStream_t s, int vdt, int cdt, const VtraceArg
     const bool al = aligned16(a.log_pi) && aligned16(a.log_mu) && (!a.next_value || aligned16(a.value)) && aligned16(a.next_value) &&
                     aligned16(a.reward) && aligned16(a.done) && aligned16(a.terminated) && aligned16(a.gamma_t) &&
                     aligned16(a.advantage) && aligned16(a.vs);
-    if (a.I > 1 && a.next_value) {  // the map-forming transposing kernel (turn_vtrace.hip)
+    if (a.I > 1 && a.next_value) {  // the map-forming transposing kernel (end of this file)
         const LaunchResult r = launch_vtrace_turn(s, vdt, cdt, a, al);
         if (r.status != 2) return r;
     }
@@ -88,4 +89,29 @@ LaunchResult launch_vtrace_scan(hipStream_t s, int vdt, int cdt, const VtraceArg
                                p.interleaved ? "vtrace_scan_interleaved" : p.lookback ? "vtrace_scan_lookback" : p.long_rows ? "vtrace_scan_long" : "vtrace_scan_short", lb_ws);
     };
     return a.next_value ? dispatch_scan<VtraceOp, VtraceArgs>(vdt, cdt, go) : dispatch_scan<VtraceShiftedOp, VtraceArgs>(vdt, cdt, go);
+}
+
+// ---- feature dims after time (I > 1): the map-forming transposing kernels of gae_interleaved.h, one policy per estimator --------
+// They are instantiated HERE, beside the I == 1 kernels, on purpose: compiled in translation units of their own (tried for build
+// time: they are most of this file's 5 minutes) the very same kernels come out 19 % longer (1842 instead of 1552 instructions for
+// the C3 instantiation: the next chunk's mask loads sink below the stores, scalar tails lose a range fact) and 9 % slower --
+// C3 8.7 -> 9.9 us, TD(lambda) 8.8 -> 9.5 us; rocprofv3 kernel averages 9.27 vs 10.12 us.  Force-inlining the kernel's lambdas
+// does not change that; what in this file's context the optimiser feeds on was not found.
+LaunchResult launch_gae_turn(hipStream_t s, int vdt, int cdt, const GaeArgs &a, bool aligned) {
+    return dispatch_turn<GaeTurn>(s, vdt, cdt, a, aligned, a.partials, "gae_scan_interleaved");
+}
+LaunchResult launch_td_lambda_turn(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, bool aligned) {
+    return dispatch_turn<TdLambdaTurn>(s, vdt, cdt, a, aligned, nullptr, "td_lambda_scan_interleaved");
+}
+LaunchResult launch_td1_turn(hipStream_t s, int vdt, int cdt, const TdLambdaArgs &a, bool aligned) {
+    return dispatch_turn<Td1Turn>(s, vdt, cdt, a, aligned, nullptr, "td1_scan_interleaved");
+}
+LaunchResult launch_vtrace_turn(hipStream_t s, int vdt, int cdt, const VtraceArgs &a, bool aligned) {
+    return dispatch_turn<VtraceTurn>(s, vdt, cdt, a, aligned, nullptr, "vtrace_scan_interleaved");
+}
+
+// outer rows of more than a team's chunk that the 1024-thread kernel takes (capi.hip AUTO)
+bool scan_turn_big_ok(int vdt, i64 T, i64 I) {
+    Plan p;
+    return turn_big_plan(1 << 20, T, I, vdt == 0 ? 4 : 2, true, p);
 }
