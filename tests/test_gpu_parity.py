@@ -257,6 +257,32 @@ def test_many_feature_rows_on_wide_blocks(shape, time_dim, dtype):
     torch.testing.assert_close(nadv.cpu(), O.normalize(O.gae(0.9, 0.9, v, nv, r, done, term, time_dim=time_dim)[0], 1e-4), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(37, 100, 30), (9, 200, 20), (21, 100, 5)], ids=lambda s: "x".join(map(str, s)))
+def test_feature_rows_fp32_values_fp64_coefficients(shape):
+    """python-float coefficients under default dtype float64 beside fp32 values: the transposing kernels keep their maps (and
+    V-trace its outputs) in double -- up to 101 KB of LDS per 1024-thread block.  Every estimator against the oracle."""
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        r, v, nv, done, term, gam, lp, lm = _rand_inputs(shape, torch.float32, seed=41)
+        oa, ovt = O.gae(0.97, 0.9, v, nv, r, done, term)
+        a, vt = F.generalized_advantage_estimate(0.97, 0.9, cu(v), cu(nv), cu(r), cu(done), cu(term))
+        assert F.last_kernel() == "gae_scan_interleaved"
+        check(a, oa, False, done)
+        check(vt, ovt, False, done)
+        ot = O.td_lambda(0.97, 0.9, nv, r, done, term)
+        t = F.td_lambda_return_estimate(0.97, 0.9, cu(nv), cu(r), cu(done), cu(term))
+        assert F.last_kernel() == "td_lambda_scan_interleaved" and t.dtype == ot.dtype
+        torch.testing.assert_close(t.cpu(), ot, rtol=1e-5, atol=1e-5)
+        ova, ovs = O.vtrace(0.97, lp, lm, v, nv, r, done, term)
+        va, vs = F.vtrace_advantage_estimate(0.97, cu(lp), cu(lm), cu(v), cu(nv), cu(r), cu(done), cu(term))
+        assert F.last_kernel() == "vtrace_scan_interleaved" and va.dtype == ova.dtype == torch.float64
+        torch.testing.assert_close(va.cpu(), ova, rtol=1e-5, atol=1e-5)   # fp32 inputs (expf): the fp32 bar
+        torch.testing.assert_close(vs.cpu(), ovs, rtol=1e-5, atol=1e-5)
+    finally:
+        torch.set_default_dtype(old)
+
+
 def test_successive_trajectories_equal_concatenation():
     """test_cost.py:14984-15135: a batch with a `terminated` at T//2-1 equals the two halves computed apart."""
     T = 64
